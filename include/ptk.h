@@ -1,0 +1,182 @@
+/* ptk.h — C ABI of the MI355X-native path-tracing kernels ("ptk").
+ *
+ * This is the drop-in boundary for the per-bounce path-tracing inner loop of
+ * zhiyi1801/Project3-CUDA-Path-Tracer-1.  Every entry point names the reference
+ * interface it replaces (file:line relative to the reference repo).  Plain C:
+ * pointers, sizes and PODs only; no C++ / torch / HIP types in any signature
+ * (a HIP stream is passed as void*).  Every function returns 0 on success or a
+ * non-zero code (a hipError_t value, or PTK_E_* below) and never throws or exits.
+ *
+ * The C++ API of the reference (src/pathtrace.h:6-9: InitDataContainer /
+ * pathtraceInit / pathtraceFree / pathtrace) is provided on top of this ABI by
+ * project3-cuda-path-tracer-1_amd/csrc/pathtrace.h with the same four signatures.
+ *
+ * Data layout (device, HBM): path and hit state are SoA-of-float4 streams, one
+ * 16-byte element per path per stream, so that every wave64 access is a fully
+ * coalesced 1 KiB transaction:
+ *   paths.o_pix  [i] = (origin.x, origin.y, origin.z, bits(pixelIndex))
+ *   paths.d_bnc  [i] = (dir.x,    dir.y,    dir.z,    bits(remainingBounces))
+ *   paths.col_pdf[i] = (color.r,  color.g,  color.b,  prevPdf)
+ *   hits.t_n     [i] = (t, normal.x, normal.y, normal.z)
+ *   hits.p_mat   [i] = (point.x, point.y, point.z, bits(materialId))
+ *   hits.uv_ids  [i] = (u, v, bits(geomID), bits(triangleID))
+ * These carry exactly the fields of PathSegment / ShadeableIntersection
+ * (src/sceneStructs.h:80-99), 48 B each.
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTK_E_BADARG   1001
+#define PTK_E_NOSCENE  1002
+#define PTK_E_PARSE    1003
+#define PTK_E_NODEVICE 1004
+
+/* enum SampleMode { BSDF, DirectLi, MIS } — src/preview.h:13 */
+enum { PTK_MODE_BSDF = 0, PTK_MODE_DIRECTLI = 1, PTK_MODE_MIS = 2 };
+/* enum GeomType — src/sceneStructs.h:11-15 */
+enum { PTK_GEOM_SPHERE = 0, PTK_GEOM_CUBE = 1, PTK_GEOM_OBJ = 2 };
+/* Material::Type — src/material.h:32-38 */
+enum { PTK_MAT_LAMBERTIAN = 0, PTK_MAT_METALLIC = 1, PTK_MAT_DIELECTRIC = 2, PTK_MAT_MICROFACET = 3, PTK_MAT_LIGHT = 4 };
+
+/* ---- interchange PODs (host side; dword-for-dword the reference's structs) ------------------- */
+
+/* struct Camera, src/sceneStructs.h:61-70 (84 B) */
+typedef struct PtkCamera {
+    int   res[2];
+    float position[3], lookAt[3], view[3], up[3], right[3];
+    float fov[2], pixelLength[2];
+} PtkCamera;
+
+/* struct Geom, src/sceneStructs.h:35-47 without translation/rotation/scale/mesh*; matrices column-major (glm::mat4) */
+typedef struct PtkGeom {
+    int   type, materialid;
+    float transform[16], inverseTransform[16], invTranspose[16];
+} PtkGeom;
+
+/* class Material, src/material.h:524-538, constant samplers only:
+ * albedo = Material::albedo (default 1, used by Light), *_s = devTexSampler::fixVal (default 0, used by the BSDFs) */
+typedef struct PtkMaterial {
+    int   type;
+    float albedo[3];
+    float albedo_s[3];
+    float rough_s, metal_s, ior;
+} PtkMaterial;
+
+/* class Triangle, src/Bounds3.hpp:250-258 (124 B) */
+typedef struct PtkTriangle {
+    float v[9], n[9], tex[6], tangent[3], bitangent[3];
+    int   geomIdx;
+} PtkTriangle;
+
+/* struct GpuBVHNode, src/BVH.h:44-50 (40 B); 6 direction-ordered copies back to back (BVH.cpp:180-239) */
+typedef struct PtkBvhNode {
+    float pMin[3], pMax[3];
+    int   start, end, miss, hit;
+} PtkBvhNode;
+
+/* class lightPrim, src/lightSample.h:26-34 */
+typedef struct PtkLight { int geomID, triangleID, type; } PtkLight;
+
+/* ---- device-side handles ------------------------------------------------------------------- */
+
+typedef struct PtkPaths { float* o_pix; float* d_bnc; float* col_pdf; } PtkPaths;   /* device pointers, 4 floats/path each */
+typedef struct PtkHits  { float* t_n;   float* p_mat; float* uv_ids;  } PtkHits;    /* device pointers, 4 floats/path each */
+
+typedef struct PtkScene PtkScene;          /* host scene + its device image (class Scene / DevScene, src/scene.h:28-85) */
+
+/* ---- scene: replaces `new Scene(file)` (src/main.cpp:86, src/scene.cpp:47-81), the camera fix-ups of
+ *      src/main.cpp:102-127,173-193, and Scene::setDevData (src/scene.cpp:479-567) ------------------ */
+
+/* Parse the scene file (same grammar and quirks as scene.cpp), build triangles, SAH BVH, threaded 6-direction BVH
+ * and the light list.  res_w/res_h/depth <= 0 keep the file's RES / DEPTH.  Host only: needs no GPU. */
+int  ptk_scene_load(const char* file, int res_w, int res_h, int depth, PtkScene** out);
+void ptk_scene_free(PtkScene* s);                       /* Scene::clear + Resource::clear (src/main.cpp:140-141) */
+const char* ptk_scene_error(const PtkScene* s);         /* message of the last PTK_E_PARSE */
+/* counts[9] = geoms, materials, triangles, bvh_size (nodes per direction), lights, traceDepth, iterations, res.x, res.y */
+int  ptk_scene_counts(const PtkScene* s, int* counts);
+int  ptk_scene_get_camera(const PtkScene* s, PtkCamera* out);
+int  ptk_scene_get_geoms(const PtkScene* s, PtkGeom* out);
+int  ptk_scene_get_materials(const PtkScene* s, PtkMaterial* out);
+int  ptk_scene_get_triangles(const PtkScene* s, PtkTriangle* out);
+int  ptk_scene_get_bvh(const PtkScene* s, PtkBvhNode* out);          /* 6 * bvh_size nodes */
+int  ptk_scene_get_lights(const PtkScene* s, PtkLight* out);
+/* Upload the scene tables to the current HIP device (DevScene::initiate, src/scene.cpp:569-663). */
+int  ptk_scene_upload(PtkScene* s);
+
+/* ---- kernels: one entry point per reference kernel (src/pathtrace.cu) ---------------------------
+ * All pointers are DEVICE pointers unless noted.  `stream` is a hipStream_t (NULL = default stream).
+ * `n` is the number of paths; when `d_n` is non-NULL the kernel reads the count from *d_n instead
+ * (device-resident count, no host round trip) and `n` is only the launch upper bound. */
+
+/* generateRayFromCamera, pathtrace.cu:135-163.  Writes res.x*res.y paths. */
+int ptk_generate_rays(const PtkCamera* cam /*host*/, int iter, int trace_depth, PtkPaths paths, void* stream);
+
+/* computeIntersections, pathtrace.cu:169-346.  valid[i] = rayValid (0/1).  Misses get t = -1.
+ * stats (optional, device, 2 x uint64): accumulates BVH node visits and triangle tests. */
+int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkHits hits, int* valid,
+                  unsigned long long* stats, void* stream);
+
+/* compact_rays, pathtrace.cu:614-631: stable (order-preserving) stream compaction of both 48-byte streams by
+ * `valid`.  Either stream may be omitted (NULL members).  The new count is written to *d_count_out (device). */
+int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkHits hits_in,
+                PtkPaths paths_out, PtkHits hits_out, int* d_count_out, void* stream);
+
+/* PTkernel / DirectLiPTkernel / MisPTkernel, pathtrace.cu:348-588, selected by `mode` (sampleMode, main.cpp:20).
+ * Shades n compacted paths in place; thread index == compacted slot index == RNG key.  img: float[3*P] (+=). */
+int ptk_shade(const PtkScene* s, int mode, int iter, int depth, int n, const int* d_n, PtkHits hits,
+              PtkPaths paths, int* valid, float* img, void* stream);
+
+/* sendImageToPBO, pathtrace.cu:32-65: ACES + gamma 1/2.2 -> uchar4 (w = 0). */
+int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char* pbo, void* stream);
+
+/* ---- render API: the C form of src/pathtrace.h:6-9 ------------------------------------------------ */
+
+int ptk_pathtrace_init(PtkScene* s);                    /* pathtraceInit(Scene*), pathtrace.cu:85-112 */
+int ptk_pathtrace_free(void);                           /* pathtraceFree(), pathtrace.cu:114-125; null-safe, repeatable */
+/* pathtrace(uchar4* pbo, int frame, int iter), pathtrace.cu:637-816.  pbo: device pointer or NULL (skip tonemap).
+ * iter is 1-based.  Accumulates into the device radiance buffer; no host synchronisation. */
+int ptk_pathtrace(unsigned char* pbo, int frame, int iter);
+int ptk_set_sample_mode(int mode);                      /* `extern SampleMode sampleMode`, main.cpp:20 / pathtrace.cu:23 */
+int ptk_get_sample_mode(void);
+/* Copy the running radiance SUM (not mean) into host memory, float[3*P], row-major x + y*W
+ * (the per-iteration cudaMemcpy of pathtrace.cu:809-810, made lazy).  Synchronises. */
+int ptk_get_image(float* host_out);
+/* Device pointer of the radiance buffer (float[3*P]) for collectives; valid until ptk_pathtrace_free. */
+int ptk_get_image_device(float** out);
+/* Device-to-device copy of the radiance buffer into caller-owned device memory (e.g. a tensor handed to RCCL). */
+int ptk_copy_image_to_device(float* dst_device);
+/* Per-bounce live-path counts of the LAST ptk_pathtrace call (counts[trace_depth+1], host); synchronises.
+ * *traced_depth = number of bounces with live paths (guiData->TracedDepth, pathtrace.cu:793-796). */
+int ptk_get_live_counts(int* counts, int* traced_depth);
+/* Total rays (sum of live paths entering the intersection stage) since ptk_pathtrace_init; synchronises. */
+int ptk_get_ray_total(unsigned long long* rays);
+/* Restrict rendering to the pixels of interleaved tiles: pixel (x,y) is traced iff
+ * ((y / tile_rows) % n_parts) == part.  (1,0,*) = whole frame.  Multi-GPU sharding, SURVEY §8e. */
+int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
+/* Pipeline selection: 0 = staged kernels (reference order), reserved values for fused variants. */
+int ptk_set_pipeline(int which);
+int ptk_stream_sync(void);
+
+/* Per-kernel device time, measured with HIP events ON THE RENDER STREAM around every launch of the ptk_pathtrace calls
+ * issued between begin and end.  ms4/launches4: [0] generate, [1] intersect, [2] shade, [3] scatter.  Diagnostic only
+ * (adds an event pair per launch): never used inside a timed region. */
+int ptk_profile_begin(void);
+int ptk_profile_end(float* ms4, int* launches4);
+/* BVH traversal counters of the intersection kernel: out2 = {node visits, triangle tests} since enabling. */
+int ptk_enable_traversal_stats(int on);
+int ptk_get_traversal_stats(unsigned long long* out2);
+
+/* HIP events on the render stream, for benchmark timing of the timed region (bench.py). */
+int ptk_timer_start(void);
+int ptk_timer_stop(float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTK_H */

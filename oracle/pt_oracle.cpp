@@ -1430,13 +1430,20 @@ int orc_compact(int n, const int* valid, void* paths, void* isects) {
 // One pathtrace() call (pathtrace.cu:637-816): accumulates into img[3*P]; live[d] = paths entering intersect at bounce d
 // (live must hold traceDepth+1 ints; unused entries are set to 0).  Returns total rays (sum of live).
 // timing[4] (optional, seconds): generate, intersect, shade, compact.
-long long orc_pathtrace(OrcScene* S, int mode, int iter, float* img, int* live, double* timing) {
+// Tile partition (the build's multi-GPU sharding; (1,0,1) = the reference's full frame): only the pixels of
+// rows with ((y / tile_rows) % n_parts) == part are traced, enumerated in row-major order of the owned rows.
+long long orc_pathtrace_tiled(OrcScene* S, int mode, int iter, int n_parts, int part, int tile_rows, float* img, int* live, double* timing) {
     const Camera& cam = S->cam;
-    int P = cam.res[0] * cam.res[1];
-    std::vector<PathSegment> paths(P); std::vector<Isect> isects(P); std::vector<int> valid(P);
+    int W = cam.res[0], H = cam.res[1];
+    std::vector<PathSegment> paths; paths.reserve((size_t)W * H / n_parts + W * tile_rows);
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    orc_generate_rays(S, iter, paths.data());
+    for (int y = 0; y < H; ++y) {
+        if (((y / tile_rows) % n_parts) != part) continue;
+        for (int x = 0; x < W; ++x) { PathSegment ps; generate_ray(cam, iter, S->traceDepth, x, y, ps); paths.push_back(ps); }
+    }
+    int P = (int)paths.size();
+    std::vector<Isect> isects(P); std::vector<int> valid(P);
     auto t1 = clk::now();
     double tg = std::chrono::duration<double>(t1 - t0).count(), ti = 0, ts = 0, tc = 0;
     int n = P, depth = 0; long long rays = 0;
@@ -1460,6 +1467,9 @@ long long orc_pathtrace(OrcScene* S, int mode, int iter, float* img, int* live, 
     }
     if (timing) { timing[0] += tg; timing[1] += ti; timing[2] += ts; timing[3] += tc; }
     return rays;
+}
+long long orc_pathtrace(OrcScene* S, int mode, int iter, float* img, int* live, double* timing) {
+    return orc_pathtrace_tiled(S, mode, iter, 1, 0, 1, img, live, timing);
 }
 void orc_stats(unsigned long long* out, int reset) { out[0] = g_stats.nodes; out[1] = g_stats.tris; if (reset) g_stats = TraverseStats(); }
 

@@ -1,0 +1,208 @@
+// dev_scene.hip — device image of the scene (DevScene::initiate / destroy, reference src/scene.cpp:569-672)
+// and the scene part of the C ABI (include/ptk.h).
+//
+// HBM layout (all read-only during rendering, replicated per GPU; a few MB at most):
+//   DevGeom[G]      144 B each : analytic primitives, matrices as 3x4 rows  -> read through scalar loads
+//   DevMaterial[M]   48 B each : constant BSDF parameters (roughness/metallic pre-clamped)
+//   DevNode[B]       32 B each : AABB + primitive range, ONE copy shared by the six traversal directions
+//   int2[6][B]        8 B each : (hit, miss) links of the six direction-ordered threaded BVHs
+//   DevTriV[T]       36 B each : world-space vertex positions (what traversal touches)
+//   DevTriA[T]       64 B each : vertex normals, texcoords, geomIdx (touched once per ray, for the final hit)
+// The reference uploads 6 full 40-byte node copies (240 B per node) and 124-byte triangles; this is 80 B per node.
+#include "ptk_internal.h"
+#include <cstring>
+
+using namespace ptk;
+
+namespace {
+
+template <typename T>
+int upload(void** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    const size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);     // never a zero-size allocation
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (!src.empty()) { e = hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice); if (e != hipSuccess) return (int)e; }
+    return 0;
+}
+
+void rows3x4(const ptk::mat4& M, float* out) {            // out[r*4+c] = M[c][r], r < 3
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out[r * 4 + c] = M.at(c, r);
+}
+float clampG(float x, float lo, float hi) { const float a = x > lo ? x : lo; return a < hi ? a : hi; }   // glm::clamp = min(max(x,lo),hi)
+
+} // namespace
+
+int DevScene::initiate(Scene& scene) {
+    destroy();
+    std::vector<DevGeom> g(scene.geoms.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+        const Geom& s = scene.geoms[i];
+        std::memset(&g[i], 0, sizeof(DevGeom));
+        g[i].type = (int)s.type; g[i].materialid = s.materialid;
+        rows3x4(s.inverseTransform, g[i].inv);
+        rows3x4(s.transform, g[i].fwd);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[i].invT[r * 3 + c] = s.invTranspose.at(c, r);
+    }
+    std::vector<DevMaterial> m(scene.materials.size());
+    for (size_t i = 0; i < m.size(); ++i) {
+        const Material& s = scene.materials[i];
+        std::memset(&m[i], 0, sizeof(DevMaterial));
+        m[i].type = (int)s.type;
+        m[i].albedo[0] = s.albedo.x; m[i].albedo[1] = s.albedo.y; m[i].albedo[2] = s.albedo.z;
+        m[i].albedo_s[0] = s.albedoSampler.x; m[i].albedo_s[1] = s.albedoSampler.y; m[i].albedo_s[2] = s.albedoSampler.z;
+        m[i].rough = clampG(s.roughnessSampler, static_cast<float>(1e-3), 1.f);     // material.h:274, 486
+        m[i].metal = clampG(s.metallicSampler, 0.f, 1.f);                           // material.h:325, 487
+        m[i].ior = s.ior;
+    }
+    const int B = scene.bvhSize;
+    std::vector<DevNode> nodes(B);
+    std::vector<int2> links((size_t)6 * B);
+    for (int i = 0; i < B; ++i) {
+        const GpuBVHNode& n = scene.gpuBVHNodes[i];
+        nodes[i] = DevNode{n.pMin.x, n.pMin.y, n.pMin.z, n.pMax.x, n.pMax.y, n.pMax.z, n.start, n.end};
+    }
+    for (int d = 0; d < 6; ++d)
+        for (int i = 0; i < B; ++i) { const GpuBVHNode& n = scene.gpuBVHNodes[(size_t)d * B + i]; links[(size_t)d * B + i] = make_int2(n.hit, n.miss); }
+    std::vector<DevTriV> tv(scene.triangles.size());
+    std::vector<DevTriA> ta(scene.triangles.size());
+    for (size_t i = 0; i < tv.size(); ++i) {
+        const Triangle& t = scene.triangles[i];
+        const ptk::vec3* v = t.v; const ptk::vec3* n = t.n;
+        tv[i] = DevTriV{{v[0].x, v[0].y, v[0].z}, {v[1].x, v[1].y, v[1].z}, {v[2].x, v[2].y, v[2].z}};
+        ta[i] = DevTriA{{n[0].x, n[0].y, n[0].z}, {n[1].x, n[1].y, n[1].z}, {n[2].x, n[2].y, n[2].z},
+                        {t.tex[0].x, t.tex[0].y}, {t.tex[1].x, t.tex[1].y}, {t.tex[2].x, t.tex[2].y}, t.geomIdx};
+    }
+    std::vector<DevLight> li;
+    for (const lightPrim& l : scene.lights) li.push_back(DevLight{l.geomID, l.triangleID, (int)l.type});
+
+    int rc;
+    if ((rc = upload(&dev_geoms, g))) return rc;
+    if ((rc = upload(&dev_materials, m))) return rc;
+    if ((rc = upload(&dev_nodes, nodes))) return rc;
+    if ((rc = upload(&dev_links, links))) return rc;
+    if ((rc = upload(&dev_triv, tv))) return rc;
+    if ((rc = upload(&dev_tria, ta))) return rc;
+    if ((rc = upload(&dev_lights, li))) return rc;
+    tri_num = (int)tv.size(); bvh_size = B;
+    uploaded = true;
+    return 0;
+}
+
+void DevScene::destroy() {
+    void** ptrs[] = {&dev_geoms, &dev_materials, &dev_nodes, &dev_links, &dev_triv, &dev_tria, &dev_lights};
+    for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    uploaded = false;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ptk_scene_load(const char* file, int res_w, int res_h, int depth, PtkScene** out) {
+    if (!file || !out) return PTK_E_BADARG;
+    PtkScene* h = new PtkScene();
+    h->scene = new Scene(file, res_w, res_h, depth);
+    *out = h;
+    if (!h->scene->ok) return PTK_E_PARSE;
+    h->scene->applyViewerCamera();
+    h->scene->buildHostData();
+    return 0;
+}
+
+void ptk_scene_free(PtkScene* s) {
+    if (!s) return;
+    if (s->owns && s->scene) { s->scene->clear(); delete s->scene; }
+    delete s;
+}
+
+const char* ptk_scene_error(const PtkScene* s) { return (s && s->scene) ? s->scene->error.c_str() : "no scene"; }
+
+int ptk_scene_counts(const PtkScene* s, int* c) {
+    if (!s || !s->scene || !c) return PTK_E_BADARG;
+    const Scene& S = *s->scene;
+    c[0] = (int)S.geoms.size(); c[1] = (int)S.materials.size(); c[2] = (int)S.triangles.size(); c[3] = S.bvhSize;
+    c[4] = (int)S.lights.size(); c[5] = S.state.traceDepth; c[6] = (int)S.state.iterations;
+    c[7] = S.state.camera.resolution.x; c[8] = S.state.camera.resolution.y;
+    return 0;
+}
+
+int ptk_scene_get_camera(const PtkScene* s, PtkCamera* o) {
+    if (!s || !s->scene || !o) return PTK_E_BADARG;
+    const Camera& c = s->scene->state.camera;
+    o->res[0] = c.resolution.x; o->res[1] = c.resolution.y;
+    const ptk::vec3* src[5] = {&c.position, &c.lookAt, &c.view, &c.up, &c.right};
+    float* dst[5] = {o->position, o->lookAt, o->view, o->up, o->right};
+    for (int k = 0; k < 5; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+    o->fov[0] = c.fov.x; o->fov[1] = c.fov.y; o->pixelLength[0] = c.pixelLength.x; o->pixelLength[1] = c.pixelLength.y;
+    return 0;
+}
+
+int ptk_scene_get_geoms(const PtkScene* s, PtkGeom* o) {
+    if (!s || !s->scene || !o) return PTK_E_BADARG;
+    for (size_t i = 0; i < s->scene->geoms.size(); ++i) {
+        const Geom& g = s->scene->geoms[i];
+        o[i].type = (int)g.type; o[i].materialid = g.materialid;
+        std::memcpy(o[i].transform, g.transform.m, 64);
+        std::memcpy(o[i].inverseTransform, g.inverseTransform.m, 64);
+        std::memcpy(o[i].invTranspose, g.invTranspose.m, 64);
+    }
+    return 0;
+}
+
+int ptk_scene_get_materials(const PtkScene* s, PtkMaterial* o) {
+    if (!s || !s->scene || !o) return PTK_E_BADARG;
+    for (size_t i = 0; i < s->scene->materials.size(); ++i) {
+        const Material& m = s->scene->materials[i];
+        o[i].type = (int)m.type;
+        o[i].albedo[0] = m.albedo.x; o[i].albedo[1] = m.albedo.y; o[i].albedo[2] = m.albedo.z;
+        o[i].albedo_s[0] = m.albedoSampler.x; o[i].albedo_s[1] = m.albedoSampler.y; o[i].albedo_s[2] = m.albedoSampler.z;
+        o[i].rough_s = m.roughnessSampler; o[i].metal_s = m.metallicSampler; o[i].ior = m.ior;
+    }
+    return 0;
+}
+
+int ptk_scene_get_triangles(const PtkScene* s, PtkTriangle* o) {
+    if (!s || !s->scene || !o) return PTK_E_BADARG;
+    for (size_t i = 0; i < s->scene->triangles.size(); ++i) {
+        const Triangle& t = s->scene->triangles[i];
+        for (int k = 0; k < 3; ++k) {
+            o[i].v[3 * k] = t.v[k].x; o[i].v[3 * k + 1] = t.v[k].y; o[i].v[3 * k + 2] = t.v[k].z;
+            o[i].n[3 * k] = t.n[k].x; o[i].n[3 * k + 1] = t.n[k].y; o[i].n[3 * k + 2] = t.n[k].z;
+            o[i].tex[2 * k] = t.tex[k].x; o[i].tex[2 * k + 1] = t.tex[k].y;
+        }
+        o[i].tangent[0] = t.tangent.x; o[i].tangent[1] = t.tangent.y; o[i].tangent[2] = t.tangent.z;
+        o[i].bitangent[0] = t.bitangent.x; o[i].bitangent[1] = t.bitangent.y; o[i].bitangent[2] = t.bitangent.z;
+        o[i].geomIdx = t.geomIdx;
+    }
+    return 0;
+}
+
+int ptk_scene_get_bvh(const PtkScene* s, PtkBvhNode* o) {
+    if (!s || !s->scene || !o) return PTK_E_BADARG;
+    for (size_t i = 0; i < s->scene->gpuBVHNodes.size(); ++i) {
+        const GpuBVHNode& n = s->scene->gpuBVHNodes[i];
+        o[i].pMin[0] = n.pMin.x; o[i].pMin[1] = n.pMin.y; o[i].pMin[2] = n.pMin.z;
+        o[i].pMax[0] = n.pMax.x; o[i].pMax[1] = n.pMax.y; o[i].pMax[2] = n.pMax.z;
+        o[i].start = n.start; o[i].end = n.end; o[i].miss = n.miss; o[i].hit = n.hit;
+    }
+    return 0;
+}
+
+int ptk_scene_get_lights(const PtkScene* s, PtkLight* o) {
+    if (!s || !s->scene || !o) return PTK_E_BADARG;
+    for (size_t i = 0; i < s->scene->lights.size(); ++i) {
+        const lightPrim& l = s->scene->lights[i];
+        o[i].geomID = l.geomID; o[i].triangleID = l.triangleID; o[i].type = (int)l.type;
+    }
+    return 0;
+}
+
+int ptk_scene_upload(PtkScene* s) {
+    if (!s || !s->scene || !s->scene->ok) return PTK_E_NOSCENE;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return PTK_E_NODEVICE;
+    s->scene->setDevData();
+    return s->scene->devError;
+}
+
+} // extern "C"

@@ -1,0 +1,98 @@
+// main.cpp — headless driver that replays the call sequence of the reference's viewer (src/main.cpp:48-227,
+// src/preview.cpp:264-296) without GLFW/GL/ImGui:
+//   Scene(file) -> camera orbit fix-ups -> InitDataContainer -> setDevData -> loop { runCuda() } -> saveImage
+// runCuda(): at iteration 0 pathtraceFree(); pathtraceInit(scene); then iteration++ and pathtrace(pbo, 0, iteration)
+// (1-based) until `iterations`, then saveImage(): mean -> ACES -> gamma -> x-flipped 8-bit image.
+// Output: binary PPM (P6) + raw float32 radiance sum (.f32); PNG needs stb/zlib which this build does not vendor.
+//
+// usage: ptk_headless SCENE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]
+#include "pathtrace.h"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+SampleMode sampleMode = MIS;        // main.cpp:20
+
+static float aces(float x) {        // utilities.h:35-43
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    float y = (x * (a * x + b)) / (x * (c * x + d) + e);
+    return y < 0.f ? 0.f : (y > 1.f ? 1.f : y);
+}
+
+static void saveImage(const Scene& scene, int iteration, const std::string& base) {   // main.cpp:146-170
+    const int W = scene.state.camera.resolution.x, H = scene.state.camera.resolution.y;
+    const float samples = (float)iteration;
+    std::vector<unsigned char> bytes((size_t)3 * W * H);
+    for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++) {
+            const ptk::vec3& s = scene.state.image[x + y * W];
+            const float pix[3] = {s.x / samples, s.y / samples, s.z / samples};
+            unsigned char* o = &bytes[3 * ((size_t)y * W + (W - 1 - x))];               // setPixel(width-1-x, y, ...)
+            for (int k = 0; k < 3; ++k) {
+                float v = std::pow(aces(pix[k]), 1 / 2.2f);
+                v = (v < 0.f ? 0.f : (v > 1.f ? 1.f : v)) * 255.f;                       // image::savePNG, image.cpp:56-73
+                o[k] = (unsigned char)v;
+            }
+        }
+    const std::string ppm = base + "." + std::to_string(iteration) + "samp.ppm";
+    if (FILE* f = std::fopen(ppm.c_str(), "wb")) {
+        std::fprintf(f, "P6\n%d %d\n255\n", W, H);
+        std::fwrite(bytes.data(), 1, bytes.size(), f);
+        std::fclose(f);
+        std::printf("Saved %s.\n", ppm.c_str());
+    }
+    const std::string raw = base + "." + std::to_string(iteration) + "samp.f32";
+    if (FILE* f = std::fopen(raw.c_str(), "wb")) {
+        std::fwrite(scene.state.image.data(), sizeof(ptk::vec3), scene.state.image.size(), f);
+        std::fclose(f);
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::printf("Usage: %s SCENEFILE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]\n", argv[0]); return 1; }
+    int iters = -1, rw = -1, rh = -1, depth = -1;
+    std::string out;
+    for (int i = 2; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--mode") && i + 1 < argc) { const char* m = argv[++i]; sampleMode = !std::strcmp(m, "bsdf") ? BSDF : (!std::strcmp(m, "direct") ? DirectLi : MIS); }
+        else if (!std::strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--res") && i + 2 < argc) { rw = std::atoi(argv[++i]); rh = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::printf("No HIP-capable devices were detected.\n"); return 2; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) == hipSuccess)
+        std::printf("Device 0: \"%s\" %s, %d CUs, core clock %d MHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+
+    Scene* scene = new Scene(argv[1], rw, rh, depth);
+    if (!scene->ok) { std::printf("%s\n", scene->error.c_str()); return 3; }
+    GuiDataContainer* guiData = new GuiDataContainer();
+    scene->applyViewerCamera();                          // main.cpp:102-127 + runCuda's camchanged block
+    InitDataContainer(guiData);
+    scene->setDevData();
+    if (scene->devError) { std::printf("scene upload failed: %d\n", scene->devError); return 4; }
+    const int total = iters > 0 ? iters : (int)scene->state.iterations;
+    if (out.empty()) out = scene->state.imageName.empty() ? std::string("render") : scene->state.imageName;
+
+    int iteration = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (true) {                                       // mainLoop -> runCuda
+        if (iteration == 0) { pathtraceFree(); pathtraceInit(scene); }
+        if (iteration < total) { iteration++; pathtrace(nullptr, 0, iteration); }
+        else break;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("%d iterations in %.3f s (%.2f ms/iteration), TracedDepth %d\n", iteration, sec, 1e3 * sec / std::max(1, iteration), guiData->TracedDepth);
+    saveImage(*scene, iteration, out);
+    pathtraceFree();
+    Resource::clear();
+    scene->clear();
+    delete scene;
+    delete guiData;
+    return 0;
+}

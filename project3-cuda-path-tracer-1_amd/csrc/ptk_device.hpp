@@ -1,0 +1,589 @@
+// ptk_device.hpp — device-side math of the path-tracing hot path for gfx950 (wave64).
+//
+// Scalar-per-lane code: one path per lane, scene constants addressed with wave-uniform
+// indices so the compiler keeps them in SGPRs (s_load), per-lane state in VGPRs.
+//
+// NUMERICS CONTRACT.  This file is compiled with -ffp-contract=off and the default
+// correctly-rounded fp32 divide/sqrt.  Every expression is written in the evaluation order
+// of the reference's host/device headers (file:line cited per function; GLM 0.9.6.3 order
+// for dot / mat*vec / normalize / mix), so each fp32 result is the IEEE-754 result of the
+// same operation sequence.  sin/cos use the "ptk sincos" specification (below) instead of
+// a platform libm: + - * only, so the result is reproducible on any IEEE machine.
+//
+// Deliberate, value-preserving simplifications (results compare == to the literal form):
+//   * mat4 * (v,0): the "+ m[3]*0" term of glm's mat4*vec4 is dropped (adds +-0);
+//   * cross((0,0,1), w) is written as (-w.y, w.x, 0) (differs only in the sign of a zero);
+//   * triangle attributes are interpolated once for the final closest hit instead of at
+//     every accepted candidate (pure function of triangle, u, v);
+//   * next-event estimation towards a cube light is skipped: in the reference it always
+//     evaluates to 0 or NaN->0 (lightSample.h:171-248 assigns no position/pdf for cubes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+namespace ptk {
+
+#define PTK_PI      3.1415926535897932384626422832795028841971f
+#define PTK_TWO_PI  6.2831853071795864769252867665590057683943f
+#define PTK_ROUGHNESS_MIN 1e-3f     // static_cast<float>(ROUGHNESS_MIN), utilities.h:28
+#define PTK_ROUGHNESS_MAX 1.f
+#define PTK_DI __host__ __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+
+PTK_DI f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTK_DI f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTK_DI f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTK_DI f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PTK_DI f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PTK_DI f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PTK_DI f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+PTK_DI f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+PTK_DI float gmin(float x, float y) { return x < y ? x : y; }          // glm::min
+PTK_DI float gmax(float x, float y) { return x > y ? x : y; }          // glm::max
+PTK_DI float smax(float a, float b) { return a < b ? b : a; }          // std::max
+PTK_DI float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+PTK_DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PTK_DI f3 cross(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+PTK_DI float length(f3 v) { return sqrtf(dot(v, v)); }
+PTK_DI f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+PTK_DI f3 reflect(f3 I, f3 N) { return I - N * dot(N, I) * 2.0f; }
+PTK_DI float mixf(float x, float y, float a) { return x + a * (y - x); }
+PTK_DI f3 mixv(f3 x, f3 y, float a) { return x + a * (y - x); }
+PTK_DI f3 mixvv(f3 x, f3 y, f3 a) { return x + a * (y - x); }
+PTK_DI float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+// ---- ptk sincos specification (same text as oracle/pt_oracle.cpp, implemented independently) -------
+//   fk = floor(x * 2/pi + 0.5);  r = ((x - fk*P1) - fk*P2) - fk*P3;  z = r*r
+//   s = r + r*z*(S1 + z*(S2 + z*S3));  c = (1 - 0.5 z) + z*z*(C1 + z*(C2 + z*C3))
+//   quadrant fk&3: 0:(s,c) 1:(c,-s) 2:(-s,-c) 3:(-c,s)
+PTK_DI void sincos_ptk(float x, float& sn, float& cs) {
+    float fk = floorf(x * 0.636619772367581343f + 0.5f);
+    float r = ((x - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188216e-8f;
+    float z = r * r;
+    float s = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    float c = (1.0f - 0.5f * z) + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    int q = ((int)fk) & 3;
+    float a = (q & 1) ? c : s;
+    float b = (q & 1) ? s : c;
+    sn = (q & 2) ? -a : a;
+    cs = (q == 1 || q == 2) ? -b : b;
+}
+
+// ---- RNG: utilhash (intersections.h:12-20), makeSeededRandomEngine (pathtrace.cu:25-29),
+//      thrust minstd_rand + uniform_real_distribution<float> ------------------------------------------
+PTK_DI uint32_t utilhash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+struct Rng { uint32_t x; };
+PTK_DI Rng make_rng(int iter, int index, int depth) {
+    uint32_t h = utilhash(0x80000000u | ((uint32_t)depth << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
+    Rng r; r.x = h % 2147483647u; if (r.x == 0u) r.x = 1u; return r;
+}
+PTK_DI float sample1D(Rng& r) {
+    // x <- 48271 x mod (2^31 - 1); the 64-bit product form equals thrust's Schrage form (exact integers)
+    uint64_t p = (uint64_t)r.x * 48271ull;
+    uint32_t lo = (uint32_t)(p & 0x7fffffffull), hi = (uint32_t)(p >> 31);
+    uint32_t x = lo + hi; if (x >= 2147483647u) x -= 2147483647u;
+    r.x = x;
+    return (float)(x - 1u) / 2147483648.0f;
+}
+// sample2D (utilities.h:54-56): second constructor argument drawn first — see oracle/pt_oracle.cpp sample2D.
+PTK_DI f2 sample2D(Rng& r) { f2 o; o.y = sample1D(r); o.x = sample1D(r); return o; }
+
+// ---- device scene tables ---------------------------------------------------------------------------
+// Analytic primitive, 36 dwords.  Matrices as 3 rows x 4 (row-major) of glm's column-major mat4: m[r*4+c] = M[c][r].
+struct DevGeom {
+    int type, materialid;
+    float inv[12];      // inverseTransform rows 0..2
+    float fwd[12];      // transform rows 0..2
+    float invT[9];      // upper 3x3 of invTranspose, row-major
+    float pad;
+};
+struct DevMaterial {    // 12 dwords
+    int type;
+    float albedo[3], albedo_s[3];
+    float rough, metal, ior;     // rough/metal already clamped like Material::BSDF does (material.h:486-487)
+    float pad[2];
+};
+struct DevNode {        // 32 B: AABB + primitive range (shared by the 6 directions)
+    float minx, miny, minz, maxx, maxy, maxz;
+    int start, end;
+};
+struct DevTriV { float v0[3], v1[3], v2[3]; };                                  // 36 B, positions only (traversal)
+struct DevTriA { float n0[3], n1[3], n2[3]; float t0[2], t1[2], t2[2]; int geomIdx; };  // 64 B, shading attributes
+struct DevLight { int geomID, triangleID, type; };
+
+struct SceneView {
+    const DevGeom* geoms;        int n_geoms;
+    const DevMaterial* mats;     int n_mats;
+    const DevNode* nodes;        int bvh_size;
+    const int2* links;           // [6][bvh_size] (hit, miss)
+    const DevTriV* triv;         const DevTriA* tria; int n_tris;
+    const DevLight* lights;      int n_lights;
+};
+
+// vec3(M * vec4(v,1)) and vec3(M * vec4(v,0)) in glm's order (type_mat4x4.inl:617-628)
+PTK_DI f3 xform_point(const float* m, f3 v) {
+    return mk3((m[0] * v.x + m[1] * v.y) + (m[2] * v.z + m[3]),
+               (m[4] * v.x + m[5] * v.y) + (m[6] * v.z + m[7]),
+               (m[8] * v.x + m[9] * v.y) + (m[10] * v.z + m[11]));
+}
+PTK_DI f3 xform_dir(const float* m, f3 v) {
+    return mk3((m[0] * v.x + m[1] * v.y) + (m[2] * v.z),
+               (m[4] * v.x + m[5] * v.y) + (m[6] * v.z),
+               (m[8] * v.x + m[9] * v.y) + (m[10] * v.z));
+}
+PTK_DI f3 xform_nrm(const float* m, f3 v) {
+    return mk3((m[0] * v.x + m[1] * v.y) + (m[2] * v.z),
+               (m[3] * v.x + m[4] * v.y) + (m[5] * v.z),
+               (m[6] * v.x + m[7] * v.y) + (m[8] * v.z));
+}
+
+// ---- primitives -----------------------------------------------------------------------------------
+// boxIntersectionTest, intersections.h:48-90.  Returns world-space distance or -1.
+PTK_DI float box_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& N) {
+    f3 qo = xform_point(g.inv, ro);
+    f3 qd = normalize(xform_dir(g.inv, rd));
+    float tmin = -1e38f, tmax = 1e38f;
+    int amin = 0, amax = 0; float smin = 0.f, smax_ = 0.f;     // normal = axis * sign (zero-initialised tmin_n/tmax_n)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float d = comp(qd, a), o = comp(qo, a);
+        float t1 = (-0.5f - o) / d;
+        float t2 = (+0.5f - o) / d;
+        float ta = gmin(t1, t2), tb = gmax(t1, t2);
+        float sg = t2 < t1 ? +1.f : -1.f;
+        if (ta > 0 && ta > tmin) { tmin = ta; amin = a; smin = sg; }
+        if (tb < tmax) { tmax = tb; amax = a; smax_ = sg; }
+    }
+    if (tmax >= tmin && tmax > 0) {
+        if (tmin <= 0) { tmin = tmax; amin = amax; smin = smax_; }
+        f3 n = mk3(amin == 0 ? smin : 0.f, amin == 1 ? smin : 0.f, amin == 2 ? smin : 0.f);
+        f3 p = qo + (tmin - .0001f) * normalize(qd);                       // getPointOnRay, intersections.h:27-29
+        P = xform_point(g.fwd, p);
+        N = normalize(xform_nrm(g.invT, n));
+        return length(ro - P);
+    }
+    return -1.f;
+}
+
+// sphereIntersectionTest, intersections.h:102-144
+PTK_DI float sphere_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& N) {
+    f3 o = xform_point(g.inv, ro);
+    f3 d = normalize(xform_dir(g.inv, rd));
+    float vd = dot(o, d);
+    float radicand = vd * vd - (dot(o, o) - 0.25f);
+    if (radicand < 0) return -1.f;
+    float sq = sqrtf(radicand);
+    float first = -vd;
+    float t1 = first + sq, t2 = first - sq;
+    float t;
+    if (t1 < 0 && t2 < 0) return -1.f;
+    else if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
+    else t = (t1 < t2) ? t2 : t1;
+    f3 obj = o + (t - .0001f) * normalize(d);
+    P = xform_point(g.fwd, obj);
+    N = normalize(xform_nrm(g.invT, obj));
+    return length(ro - P);
+}
+
+// Bounds3::IntersectP(ray, t), Bounds3.hpp:162-189
+PTK_DI bool aabb_test(const DevNode& nd, f3 o, f3 d, f3 inv, float& t) {
+    float tEnter = -FLT_MAX, tExit = FLT_MAX;
+    {
+        if (d.x == 0) { if (o.x < nd.minx || o.x > nd.maxx) return false; }
+        else { float tMax = (nd.maxx - o.x) * inv.x, tMin = (nd.minx - o.x) * inv.x;
+               if (d.x < 0) { float s = tMax; tMax = tMin; tMin = s; }
+               tEnter = tMin > tEnter ? tMin : tEnter; tExit = tMax < tExit ? tMax : tExit; }
+    }
+    {
+        if (d.y == 0) { if (o.y < nd.miny || o.y > nd.maxy) return false; }
+        else { float tMax = (nd.maxy - o.y) * inv.y, tMin = (nd.miny - o.y) * inv.y;
+               if (d.y < 0) { float s = tMax; tMax = tMin; tMin = s; }
+               tEnter = tMin > tEnter ? tMin : tEnter; tExit = tMax < tExit ? tMax : tExit; }
+    }
+    {
+        if (d.z == 0) { if (o.z < nd.minz || o.z > nd.maxz) return false; }
+        else { float tMax = (nd.maxz - o.z) * inv.z, tMin = (nd.minz - o.z) * inv.z;
+               if (d.z < 0) { float s = tMax; tMax = tMin; tMin = s; }
+               tEnter = tMin > tEnter ? tMin : tEnter; tExit = tMax < tExit ? tMax : tExit; }
+    }
+    t = tEnter;
+    return tEnter <= tExit && tExit > 0;
+}
+
+// Triangle::getInterSect, Bounds3.hpp:298-326
+PTK_DI bool tri_test(const DevTriV& T, f3 o, f3 d, float& t, float& u, float& v) {
+    f3 v0 = mk3(T.v0[0], T.v0[1], T.v0[2]);
+    f3 e1 = mk3(T.v1[0], T.v1[1], T.v1[2]) - v0;
+    f3 e2 = mk3(T.v2[0], T.v2[1], T.v2[2]) - v0;
+    f3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    if (det == 0) return false;
+    float invDet = 1 / det;
+    f3 tvec = o - v0;
+    u = dot(tvec, pvec); u *= invDet;
+    f3 qvec = cross(tvec, e1);
+    v = dot(d, qvec); v *= invDet;
+    t = dot(e2, qvec); t *= invDet;
+    if (t < 0 || u < 0 || v < 0 || (1 - u - v) < 0) return false;
+    return true;
+}
+
+PTK_DI int mtbvh_dir(f3 d) {          // pathtrace.cu:242-244
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int k = ((ax > ay) && (ax > az)) ? 0 : (ay > az ? 1 : 2);
+    return k + (comp(d, k) > 0 ? 0 : 3);
+}
+
+struct Hit {
+    float t; f3 n; f3 p; f2 uv; int mat, geom, tri;
+};
+
+// computeIntersections body (pathtrace.cu:191-343) for one ray.  Returns rayValid.
+template <bool STATS>
+PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
+    float t_min = FLT_MAX;
+    int hit_geom = -1, tri_id = -1;
+    f3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
+    float bu = 0.f, bv = 0.f;
+    float t = -1.f;
+    for (int i = 0; i < S.n_geoms; ++i) {                       // wave-uniform loop: geom record lives in SGPRs
+        const DevGeom& g = S.geoms[i];
+        f3 tp, tn;
+        if (g.type == 1) t = box_test(g, ro, rd, tp, tn);
+        else if (g.type == 0) t = sphere_test(g, ro, rd, tp, tn);
+        if (t > 0.0f && t_min > t) { t_min = t; hit_geom = i; P = tp; N = tn; }
+    }
+    // threaded (stackless) BVH walk over the direction-ordered links (pathtrace.cu:236-279)
+    const int2* links = S.links + (size_t)mtbvh_dir(rd) * S.bvh_size;
+    f3 inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    int idx = 0;
+    while (idx != -1) {
+        if (STATS) nodeVisits++;
+        const DevNode nd = S.nodes[idx];
+        const int2 lk = links[idx];
+        float tEnter;
+        if (!aabb_test(nd, ro, rd, inv, tEnter) || tEnter > t_min) { idx = lk.y; continue; }
+        if (nd.end - nd.start <= 1) {
+            for (int k = nd.start; k < nd.end; ++k) {
+                float tt, u, v;
+                if (STATS) triTests++;
+                if (tri_test(S.triv[k], ro, rd, tt, u, v) && t_min > tt) { t_min = tt; tri_id = k; bu = u; bv = v; }
+            }
+        }
+        idx = lk.x;
+    }
+    if (tri_id >= 0) {
+        const DevTriV& V = S.triv[tri_id];
+        const DevTriA& A = S.tria[tri_id];
+        float w = 1 - bu - bv;
+        hit_geom = A.geomIdx;
+        P = w * mk3(V.v0[0], V.v0[1], V.v0[2]) + bu * mk3(V.v1[0], V.v1[1], V.v1[2]) + bv * mk3(V.v2[0], V.v2[1], V.v2[2]);
+        N = w * mk3(A.n0[0], A.n0[1], A.n0[2]) + bu * mk3(A.n1[0], A.n1[1], A.n1[2]) + bv * mk3(A.n2[0], A.n2[1], A.n2[2]);
+        h.uv.x = gclamp(w * A.t0[0] + bu * A.t1[0] + bv * A.t2[0], 0.f, 1.f);
+        h.uv.y = gclamp(w * A.t0[1] + bu * A.t1[1] + bv * A.t2[1], 0.f, 1.f);
+    } else {
+        h.uv.x = 0.f; h.uv.y = 0.f;
+    }
+    if (hit_geom == -1) { h.t = -1.0f; return 0; }
+    h.t = t_min; h.p = P; h.n = normalize(N);
+    h.mat = S.geoms[hit_geom].materialid; h.geom = hit_geom; h.tri = tri_id;
+    return 1;
+}
+
+// LightSampler::occulusionTest, lightSample.h:59-139
+PTK_DI bool occluded(const SceneView& S, f3 ori, f3 dir, f3 des) {
+    float minT = length(des - ori);
+    float t = 0.f;
+    for (int i = 0; i < S.n_geoms; ++i) {
+        const DevGeom& g = S.geoms[i];
+        f3 tp, tn;
+        if (g.type == 1) t = box_test(g, ori, dir, tp, tn);
+        else if (g.type == 0) t = sphere_test(g, ori, dir, tp, tn);
+        if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
+    }
+    const int2* links = S.links + (size_t)mtbvh_dir(dir) * S.bvh_size;
+    f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    int idx = 0;
+    while (idx != -1) {
+        const DevNode nd = S.nodes[idx];
+        const int2 lk = links[idx];
+        float tEnter;
+        if (!aabb_test(nd, ori, dir, inv, tEnter) || tEnter > minT) { idx = lk.y; continue; }
+        if (nd.end - nd.start <= 1) {
+            for (int k = nd.start; k < nd.end; ++k) {
+                float tt, u, v;
+                if (tri_test(S.triv[k], ori, dir, tt, u, v) && minT - 1e-5f > tt && (double)fabsf(tt - minT) > 1e-4) return true;
+            }
+        }
+        idx = lk.x;
+    }
+    return false;
+}
+
+// ---- shading math ---------------------------------------------------------------------------------
+PTK_DI void pixar_basis(f3 n, f3& xp, f3& yp) {                   // utilities.h:188-200
+    float sz = n.z >= 0 ? 1.f : -1.f;
+    float a = 1.0f / (sz + n.z);
+    float sx = sz * n.x;
+    float b = n.x * n.y * a;
+    xp = mk3(sx * n.x * a - 1.f, sz * b, sx);
+    yp = mk3(b, n.y * n.y * a - sz, n.y);
+}
+PTK_DI f3 sample_hemisphere_cosine(f3 n, f2 r) {                  // utilities.h:224-235 + ONB 136-146
+    f3 u, v; f3 w = normalize(n);
+    pixar_basis(n, u, v);
+    float sinTheta = sqrtf(r.x), cosTheta = sqrtf(1 - r.x);
+    float sp, cp; sincos_ptk(PTK_TWO_PI * r.y, sp, cp);
+    float lx = sinTheta * cp, ly = sinTheta * sp;
+    return lx * u + ly * v + cosTheta * w;
+}
+PTK_DI float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+PTK_DI float nan_to_zero(float x) { return (x != x || __builtin_isinf(x)) ? 0.f : x; }   // math::processNAN utilities.h:275-283
+PTK_DI f3 nan_to_zero(f3 v) { return mk3(nan_to_zero(v.x), nan_to_zero(v.y), nan_to_zero(v.z)); }
+PTK_DI f3 fresnel_schlick(f3 f0, float c) { return f0 + (mk3(1.f, 1.f, 1.f) - f0) * pow5(1 - c); }
+PTK_DI float fresnel_maxwell(float c1, float ior1, float ior2) {   // utilities.h:332-342
+    float s1 = sqrtf(gmax(1 - c1 * c1, 0.f));
+    float s2 = s1 * ior1 / ior2;
+    if (s2 > 1) return 1.f;
+    float c2 = sqrtf(gmax(1 - s2 * s2, 0.f));
+    float rpa = (ior1 * c2 - ior2 * c1) / (ior1 * c2 + ior2 * c1);
+    float rpe = (ior1 * c1 - ior2 * c2) / (ior1 * c1 + ior2 * c2);
+    return (rpa * rpa + rpe * rpe) / 2.f;
+}
+PTK_DI f3 sample_normal_ggx(f3 n, f3 wo, float alpha, f2 r) {      // utilities.h:351-377
+    f3 t, b; pixar_basis(n, t, b);
+    f3 wl = mk3(t.x * wo.x + t.y * wo.y + t.z * wo.z, b.x * wo.x + b.y * wo.y + b.z * wo.z, n.x * wo.x + n.y * wo.y + n.z * wo.z);
+    f3 wh = normalize(mk3(alpha * wl.x, alpha * wl.y, 1.f * wl.z));
+    if (wh.z < 0) wh = wh * -1.f;
+    f3 T1 = (wh.z < 0.99999f) ? normalize(mk3(-wh.y, wh.x, 0.f)) : mk3(1.f, 0.f, 0.f);
+    f3 T2 = cross(wh, T1);
+    float radius = sqrtf(r.x);
+    float st, ct; sincos_ptk(PTK_TWO_PI * r.y, st, ct);
+    float px = radius * ct, py = radius * st;
+    float h = sqrtf(1 - px * px);
+    float lx = (1 + wh.z) / 2.f;
+    py = (1 - lx) * h + lx * py;
+    float pz = sqrtf(gmax(0.f, 1.f - (px * px + py * py)));
+    f3 nh = px * T1 + py * T2 + pz * wh;
+    f3 l = mk3(alpha * nh.x, alpha * nh.y, gmax(1e-6f, nh.z));
+    return normalize(mk3(t.x * l.x + b.x * l.y + n.x * l.z, t.y * l.x + b.y * l.y + n.y * l.z, t.z * l.x + b.z * l.y + n.z * l.z));
+}
+PTK_DI float smith_g2(float a2, float NoV, float NoL) {
+    float denom = NoL * sqrtf(NoV * NoV * (1.f - a2) + a2) + NoV * sqrtf(NoL * NoL * (1.f - a2) + a2);
+    return (2.f * NoV * NoL) / denom;
+}
+PTK_DI float smith_g1(float a2, float NoV) {
+    float denom = sqrtf(NoV * NoV * (1 - a2) + a2) + NoV;
+    return (2 * NoV) / denom;
+}
+PTK_DI float ggx_d(float c, float a2) {
+    if (c < 1e-6f) return 0.f;
+    float denom = c * c * (a2 - 1.f) + 1.f;
+    denom = denom * denom * PTK_PI;
+    return a2 / denom;
+}
+PTK_DI float power_heuristic(float f, float g) { return (f * f) / (f * f + g * g); }
+
+PTK_DI f3 microfacet_bsdf(f3 n, f3 wo, f3 wi, f3 albedo, float rough) {       // material.h:246-261
+    float a2 = rough * rough;
+    float cosO = dot(n, wo), cosI = dot(n, wi);
+    if ((double)(cosO * cosI) < 1e-7) return mk3(0, 0, 0);
+    f3 wm = normalize(wo + wi);
+    float D = ggx_d(dot(wm, n), a2);
+    float G2 = smith_g2(rough, cosO, cosI);
+    f3 F = fresnel_schlick(albedo, dot(wo, wm));
+    return F * D * G2 / gmax(4 * cosO * cosI, 1e-8f);
+}
+PTK_DI float microfacet_pdf(f3 n, f3 wo, f3 wi, float rough) {                // material.h:263-271
+    float a2 = rough * rough;
+    float cosO = dot(n, wo);
+    f3 wm = normalize(wo + wi);
+    float D = ggx_d(dot(wm, n), a2);
+    float G1 = smith_g1(rough, cosO);
+    return G1 * D / gmax(4 * dot(wo, n), 1e-8f);
+}
+PTK_DI f3 metallic_bsdf(f3 n, f3 wo, f3 wi, f3 albedo, float rough, float metal) {   // material.h:296-310
+    float a2 = rough * rough;
+    float cosO = dot(n, wo), cosI = dot(n, wi);
+    if ((double)(cosO * cosI) < 1e-7) return mk3(0, 0, 0);
+    f3 wm = normalize(wo + wi);
+    float D = ggx_d(dot(wm, n), a2);
+    float G2 = smith_g2(rough, cosO, cosI);
+    f3 F = fresnel_schlick(mixv(mk3(0.08f, 0.08f, 0.08f), albedo, metal), dot(wo, wm));
+    float spec = D * G2 / gmax(4 * cosO * cosI, 1e-8f);
+    f3 diff = (1.f - metal) * albedo * 1.f / PTK_PI;
+    return mixvv(diff, mk3(spec, spec, spec), F);
+}
+PTK_DI float metallic_pdf(f3 n, f3 wo, f3 wi, float rough, float metal) {     // material.h:312-320
+    float a2 = rough * rough;
+    float cosO = dot(n, wo);
+    f3 wm = normalize(wo + wi);
+    float D = ggx_d(dot(wm, n), a2);
+    float G1 = smith_g1(rough, cosO);
+    return mixf(dot(wi, n) * 1.f / PTK_PI, G1 * D / gmax(4 * dot(wo, n), 1e-8f), 1.f / (2.f - metal));
+}
+
+struct Scatter { f3 bsdf; float pdf; f3 dir; };
+
+// Material::scatterSample, material.h:450-481.  wo = incident direction (into the surface).
+PTK_DI void scatter_sample(const DevMaterial& m, f3 n, f3 wo, Scatter& s, Rng& rng) {
+    s.pdf = 0.f; s.bsdf = mk3(0, 0, 0); s.dir = mk3(0, 0, 0);
+    f3 albedo = mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+    switch (m.type) {
+    case 0: {
+        s.bsdf = albedo / PTK_PI;
+        s.dir = sample_hemisphere_cosine(n, sample2D(rng));
+        s.pdf = dot(s.dir, n) / PTK_PI;
+        break; }
+    case 1: {
+        float r = sample1D(rng);
+        if (r < 1.f / (2.f - m.metal)) {
+            f3 wm = sample_normal_ggx(n, -1.f * wo, m.rough * m.rough, sample2D(rng));
+            s.dir = reflect(wo, wm);
+        } else {
+            s.dir = sample_hemisphere_cosine(n, sample2D(rng));
+        }
+        if (dot(-1.f * wo, n) < 0 || dot(s.dir, n) < 0) { s.bsdf = mk3(0, 0, 0); s.pdf = 0; return; }
+        s.bsdf = metallic_bsdf(n, -1.f * wo, s.dir, albedo, m.rough, m.metal);
+        s.pdf = metallic_pdf(n, -1.f * wo, s.dir, m.rough, m.metal);
+        break; }
+    case 2: {
+        float ior1, ior2;
+        float won = dot(wo, n);
+        if (won < 0) { ior1 = 1; ior2 = m.ior; } else { ior2 = 1; ior1 = m.ior; }
+        float F = fresnel_maxwell(fabsf(won), ior1, ior2);
+        f3 nn = won < 0 ? n : -n;                                  // getReflectDir / getRefractDir, utilities.h:290-320
+        if (sample1D(rng) < F) {
+            s.dir = wo - 2.f * (nn * dot(wo, nn));
+            s.bsdf = albedo;
+        } else {
+            f3 perp = (wo - dot(wo, nn) * nn) * (ior1 / ior2);
+            f3 para = (-1 * sqrtf(1 - (perp.x * perp.x + perp.y * perp.y + perp.z * perp.z))) * nn;
+            s.dir = perp + para;
+            s.bsdf = albedo * (ior2 * ior2) / (ior1 * ior1);
+        }
+        s.pdf = 1.f;
+        s.bsdf = s.bsdf / fabsf(dot(s.dir, n));
+        break; }
+    case 3: {
+        f3 wm = sample_normal_ggx(n, -1.f * wo, m.rough, sample2D(rng));
+        s.dir = reflect(wo, wm);
+        if (dot(s.dir, n) * dot(-1.f * wo, n) < 0) { s.bsdf = mk3(0, 0, 0); s.pdf = 0; return; }
+        s.bsdf = microfacet_bsdf(n, -1.f * wo, s.dir, albedo, m.rough);
+        s.pdf = microfacet_pdf(n, -1.f * wo, s.dir, m.rough);
+        break; }
+    case 4:
+        s.bsdf = mk3(m.albedo[0], m.albedo[1], m.albedo[2]); s.pdf = 1.f; break;
+    default: break;
+    }
+}
+PTK_DI f3 mat_bsdf(const DevMaterial& m, f3 n, f3 wo, f3 wi) {       // Material::BSDF, material.h:483-501
+    f3 albedo = mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+    switch (m.type) {
+    case 0: return albedo / PTK_PI;
+    case 3: return microfacet_bsdf(n, -1.f * wo, wi, albedo, m.rough);
+    case 1: return metallic_bsdf(n, -1.f * wo, wi, albedo, m.rough, m.metal);
+    default: return mk3(0, 0, 0);
+    }
+}
+PTK_DI float mat_pdf(const DevMaterial& m, f3 n, f3 wo, f3 wi) {     // Material::pdf, material.h:503-521
+    switch (m.type) {
+    case 0: return dot(wi, n) / PTK_PI;
+    case 3: return microfacet_pdf(n, -1.f * wo, wi, m.rough);
+    case 1: return metallic_pdf(n, -1.f * wo, wi, m.rough, m.metal);
+    default: return 0.f;
+    }
+}
+
+// ---- light sampling (lightSample.h) -----------------------------------------------------------------
+struct LightRec { f3 pos, emit; float pdf; bool is_zero; };
+
+// LightSampler::lightPDF, lightSample.h:141-169
+PTK_DI float light_pdf(const SceneView& S, f3 viewPos, f3 lightPos, f3 normal, int triID, int geomID) {
+    float pdf = -1.f;
+    float L = (float)S.n_lights;
+    if (triID >= 0) {
+        const DevTriV& T = S.triv[triID];
+        f3 v0 = mk3(T.v0[0], T.v0[1], T.v0[2]);
+        float area = length(cross(mk3(T.v1[0], T.v1[1], T.v1[2]) - v0, mk3(T.v2[0], T.v2[1], T.v2[2]) - v0)) / 2.f;
+        pdf = 1.f / L;
+        f3 dl = lightPos - viewPos;
+        pdf = pdf * dot(dl, dl) / (area * fabsf(dot(normalize(viewPos - lightPos), normal)));
+    }
+    const DevGeom& g = S.geoms[geomID];
+    if (g.type == 0) {
+        f3 vl = xform_point(g.inv, viewPos);
+        float s2 = (0.5f * 0.5f) / dot(vl, vl);
+        float cmax = sqrtf(smax(0.0f, 1.0f - s2));
+        pdf = 1.0f / (PTK_TWO_PI * (1 - cmax) * L);
+    }
+    return pdf;
+}
+
+// LightSampler::lightSample, lightSample.h:171-248.  rng is a COPY (by-value parameter in the reference).
+PTK_DI void light_sample(const SceneView& S, const DevMaterial* mats, f3 viewPos, Rng rng, LightRec& rec) {
+    rec.pos = mk3(0, 0, 0); rec.emit = mk3(0, 0, 0); rec.pdf = 0.f; rec.is_zero = true;
+    int Li = S.n_lights;
+    if (Li == 0) return;
+    float L = (float)Li;
+    int lightID = (int)gmin(sample1D(rng) * L, L - 1.f);
+    DevLight light = S.lights[lightID];
+    const DevGeom& geom = S.geoms[light.geomID];
+    f3 lightPos = mk3(0, 0, 0); float pdf = 0.f;
+    if (light.triangleID >= 0) {
+        f2 r = sample2D(rng);
+        float tt = sqrtf(r.x);
+        float u = 1.f - tt, v = tt * (1.f - r.y);
+        const DevTriV& T = S.triv[light.triangleID];
+        const DevTriA& A = S.tria[light.triangleID];
+        f3 v0 = mk3(T.v0[0], T.v0[1], T.v0[2]), v1 = mk3(T.v1[0], T.v1[1], T.v1[2]), v2 = mk3(T.v2[0], T.v2[1], T.v2[2]);
+        float w = 1 - u - v;
+        lightPos = u * v0 + v * v1 + w * v2;
+        f3 normal = normalize(u * mk3(A.n0[0], A.n0[1], A.n0[2]) + v * mk3(A.n1[0], A.n1[1], A.n1[2]) + w * mk3(A.n2[0], A.n2[1], A.n2[2]));
+        float area = length(cross(v1 - v0, v2 - v0)) / 2.f;
+        pdf = 1.f / L;
+        f3 dl = lightPos - viewPos;
+        pdf = pdf * dot(dl, dl) / (area * fabsf(dot(normalize(viewPos - lightPos), normal)));
+    } else if (light.type == 0) {
+        f2 xi = sample2D(rng);
+        f3 vl = xform_point(geom.inv, viewPos);
+        f3 c2r = normalize(mk3(0.f - vl.x, 0.f - vl.y, 0.f - vl.z));
+        f3 tan, bit; pixar_basis(c2r, tan, bit);
+        float s2 = (0.5f * 0.5f) / dot(vl, vl);
+        float cmax = sqrtf(smax(0.0f, 1.0f - s2));
+        float cosT = (1.0f - xi.x) + xi.x * cmax;
+        float sinT = sqrtf(smax(0.f, 1.0f - cosT * cosT));
+        float phi = xi.y * PTK_TWO_PI;
+        float dc = length(mk3(0.f - vl.x, 0.f - vl.y, 0.f - vl.z));
+        float ds = dc * cosT - sqrtf(smax(0.0f, 0.5f * 0.5f - dc * dc * sinT * sinT));
+        float sinA = ds * sinT / 0.5f;
+        float cosA = sqrtf(gmax(0.f, 1.f - sinA * sinA));
+        float sp, cp; sincos_ptk(phi, sp, cp);
+        f3 nObj = sinA * cp * tan + sinA * sp * bit + cosA * -c2r;
+        f3 pObj = nObj * 0.5f;
+        lightPos = xform_point(geom.fwd, pObj);
+        pdf = 1.0f / (PTK_TWO_PI * (1 - cmax) * L);
+    } else {
+        // cube light: the reference assigns neither position nor pdf; the sample evaluates to 0 / NaN->0 whatever
+        // the occlusion test returns (see file header), so the shadow ray is not traced.
+        rec.pdf = 0.f; return;
+    }
+    f3 rayDir = normalize(lightPos - viewPos);
+    if (occluded(S, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = mk3(0, 0, 0); rec.pdf = -1.f; return; }
+    const DevMaterial& lm = mats[geom.materialid];
+    rec.emit = mk3(lm.albedo[0], lm.albedo[1], lm.albedo[2]);
+    rec.pdf = pdf; rec.pos = lightPos; rec.is_zero = false;
+}
+
+} // namespace ptk

@@ -1,0 +1,48 @@
+// ptk_internal.h — glue shared by the .hip translation units (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ptk.h"
+#include "scene.h"
+#include "ptk_device.hpp"
+
+struct PtkScene {
+    Scene* scene = nullptr;
+    bool owns = true;
+};
+
+namespace ptk {
+
+// device view of an uploaded scene (pointers into DevScene's buffers), passed to kernels by value
+inline SceneView dev_view(const ::Scene& s) {
+    SceneView d;
+    const ::DevScene& t = s.tempDevScene;
+    d.geoms = (const DevGeom*)t.dev_geoms;       d.n_geoms = (int)s.geoms.size();
+    d.mats = (const DevMaterial*)t.dev_materials; d.n_mats = (int)s.materials.size();
+    d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
+    d.links = (const int2*)t.dev_links;
+    d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
+    d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
+    return d;
+}
+
+// pipeline-internal launchers (ptk_kernels.hip); all asynchronous on `st`
+struct Workspace {               // per-render-context scratch, device memory
+    int* agg_a = nullptr;        // per-block hit counts of the intersect stage
+    int* agg_b = nullptr;        // per-block survivor counts of the shade stage
+    int* valid_a = nullptr;      // rayValid after intersect   [capacity]
+    int* valid_b = nullptr;      // rayValid after shading     [capacity]
+    int* counts = nullptr;       // live paths entering bounce d, d = 0..traceDepth  (device)
+    unsigned long long* ray_total = nullptr;   // sum of counts over all iterations (device)
+    unsigned long long* stats = nullptr;       // optional node/triangle counters
+    int capacity = 0;
+};
+
+int launch_generate(const ::Camera& cam, int iter, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
+                    int n_local, int* d_count0, hipStream_t st);
+int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
+                         PtkHits hits, float* img, const Workspace& ws, hipStream_t st);
+int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
+                                  PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool));
+int local_path_count(int W, int H, int n_parts, int part, int tile_rows);
+
+} // namespace ptk

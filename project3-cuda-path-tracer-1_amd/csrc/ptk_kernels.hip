@@ -1,0 +1,441 @@
+// ptk_kernels.hip — HIP kernels of the path-tracing hot path for gfx950 + their C-ABI launchers.
+//
+// One kernel per reference kernel (src/pathtrace.cu), re-designed for CDNA4:
+//   k_generate   <- generateRayFromCamera (135-163)
+//   k_intersect  <- computeIntersections  (169-346)
+//   k_shade<M>   <- PTkernel / DirectLiPTkernel / MisPTkernel (348-588)
+//   k_count + k_scatter <- compact_rays (614-631; thrust exclusive_scan + 2x scatter_if + 2 blocking D2H)
+//   k_tonemap    <- sendImageToPBO (32-65)
+// Differences that matter on MI355X:
+//   * 256-thread blocks = 4 wave64; all state streams are float4 SoA (16 B/lane, 1 KiB per wave access);
+//   * scene constants (primitives, materials) are read with wave-uniform indices -> scalar loads / SGPR operands;
+//   * path counts never leave the device: every kernel takes an optional device-resident count, and the
+//     stable compaction is wave-ballot + block prefix + a per-block aggregate table, so a whole iteration is
+//     enqueued without a single host synchronisation;
+//   * in the render pipeline the first compaction of each bounce is *virtual*: the shading kernel derives each
+//     path's compacted slot (the reference's RNG key) from the intersect stage's flags and aggregates, so hit
+//     records are never moved, and surviving path state is moved once per bounce.
+#include "ptk_internal.h"
+
+using namespace ptk;
+
+#define PTK_BLOCK 256
+#define PTK_WAVES (PTK_BLOCK / 64)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// block-level primitives
+// ------------------------------------------------------------------------------------------------------------------
+// exclusive prefix of `flag` over the block in thread order; `total` = number of set flags in the block
+__device__ __forceinline__ int block_excl_prefix(int flag, int& total) {
+    __shared__ int wsum[PTK_WAVES];
+    const unsigned long long bal = __ballot(flag != 0);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wid] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PTK_WAVES; ++w) { const int c = wsum[w]; off += (w < wid) ? c : 0; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + within;
+}
+
+// sum of agg[0 .. b): every block reduces its predecessors' aggregates itself (<= 10 loads/thread at 800x800)
+__device__ __forceinline__ int prior_blocks(const int* __restrict__ agg, int b) {
+    __shared__ int red[PTK_WAVES];
+    int s = 0;
+    for (int k = threadIdx.x; k < b; k += PTK_BLOCK) s += agg[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < PTK_WAVES; ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ __forceinline__ void st4(float* p, int i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+
+struct DevCamera { int W, H; f3 pos, view, up, right; float plx, ply; };
+
+// ------------------------------------------------------------------------------------------------------------------
+// generateRayFromCamera, pathtrace.cu:135-163.  Path j -> pixel (x,y) through the tile partition.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter, int traceDepth, PtkPaths paths,
+                                                         int n_parts, int part, int tile_rows, int n_local, int* count0) {
+    const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (j == 0 && count0) *count0 = n_local;
+    if (j >= n_local) return;
+    const int lr = j / cam.W, x = j - lr * cam.W;
+    const int y = ((lr / tile_rows) * n_parts + part) * tile_rows + (lr % tile_rows);
+    Rng rng = make_rng(x, y, iter);                       // argument order of pathtrace.cu:148: (iter:=x, index:=y, depth:=iter)
+    const f2 r = sample2D(rng);
+    const float fx = static_cast<float>(static_cast<float>(x) + ((double)r.x - 0.5) - cam.W * 0.5f);
+    const float fy = static_cast<float>(static_cast<float>(y) + ((double)r.y - 0.5) - cam.H * 0.5f);
+    const f3 d = normalize(cam.view - cam.right * cam.plx * fx - cam.up * cam.ply * fy);
+    st4(paths.o_pix, j, make_float4(cam.pos.x, cam.pos.y, cam.pos.z, __int_as_float(x + y * cam.W)));
+    st4(paths.d_bnc, j, make_float4(d.x, d.y, d.z, __int_as_float(traceDepth)));
+    st4(paths.col_pdf, j, make_float4(1.f, 1.f, 1.f, -1.f));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// computeIntersections, pathtrace.cu:169-346
+// ------------------------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
+                                                          PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
+                                                          unsigned long long* ray_total, unsigned long long* stats) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * PTK_BLOCK >= n) return;
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    if (i == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
+    int flag = 0;
+    unsigned nv = 0, nt = 0;
+    if (i < n) {
+        const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i);
+        Hit h;
+        flag = closest_hit<STATS>(S, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), h, nv, nt);
+        if (flag) {
+            st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+            st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+            st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+        } else {
+            st4(hits.t_n, i, make_float4(-1.f, 0.f, 0.f, 0.f));
+        }
+        valid[i] = flag;
+    }
+    if (agg) {
+        int total;
+        (void)block_excl_prefix(flag, total);
+        if (threadIdx.x == 0) agg[b] = total;
+    }
+    if (STATS && stats) {
+        unsigned long long a = nv, c = nt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// shading: PTkernel (405-498), DirectLiPTkernel (348-403), MisPTkernel (500-588) for one path.
+// `slot` is the compacted index of the path == the RNG key of the reference.  Returns rayValid.
+// ------------------------------------------------------------------------------------------------------------------
+struct PathRegs { f3 o, d, col; int pix, bounces; float prevPdf; };
+
+__device__ __forceinline__ void add_radiance(float* __restrict__ img, int pix, f3 c) {
+    float* p = img + 3 * (size_t)pix;          // one live path per pixel: plain read-modify-write, no atomics
+    p[0] += c.x; p[1] += c.y; p[2] += c.z;
+}
+
+template <int MODE>
+__device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot, int depth, const Hit& h, PathRegs& p, float* __restrict__ img) {
+    if (h.t <= 0.f) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
+    const DevMaterial& m = S.mats[h.mat];
+    Rng rng = make_rng(iter, slot, depth);
+    if (MODE == PTK_MODE_DIRECTLI) {
+        if (m.type == PTK_MAT_LIGHT) {
+            p.col = p.col * mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+            p.bounces = 0;
+            add_radiance(img, p.pix, nan_to_zero(p.col));
+            return 0;
+        }
+        LightRec li;
+        light_sample(S, S.mats, h.p, rng, li);
+        if (li.pdf <= 0) { p.col = p.col * 0.f; return 0; }
+        const f3 wi = normalize(li.pos - h.p);
+        const f3 f = mat_bsdf(m, h.n, p.d, wi);
+        p.col = p.col * (f * li.emit * gmax(dot(wi, h.n), 0.f) / li.pdf);
+        add_radiance(img, p.pix, nan_to_zero(p.col));
+        return 0;
+    }
+    Scatter s;
+    scatter_sample(m, h.n, p.d, s, rng);
+    if (s.pdf == 0) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
+    if (m.type == PTK_MAT_LIGHT) {
+        float weight = 1.f;
+        if (MODE == PTK_MODE_MIS && p.prevPdf > 0) {
+            const float lp = light_pdf(S, p.o, h.p, h.n, h.tri, h.geom);
+            weight = power_heuristic(p.prevPdf, lp);
+        }
+        if (MODE == PTK_MODE_MIS) p.col = p.col * ((s.bsdf / s.pdf) * weight);
+        else p.col = p.col * (s.bsdf / s.pdf);
+        p.bounces = 0;
+        add_radiance(img, p.pix, nan_to_zero(p.col));
+        return 0;
+    }
+    const bool isDelta = (m.type == PTK_MAT_DIELECTRIC);
+    if (MODE == PTK_MODE_MIS && !isDelta) {
+        LightRec li;
+        light_sample(S, S.mats, h.p, rng, li);                        // rng by value: the path's stream does not advance
+        if (!li.is_zero) {
+            const f3 wi = normalize(li.pos - h.p);
+            const float bp = mat_pdf(m, h.n, p.d, wi);
+            const float lp = li.pdf;
+            const f3 f = mat_bsdf(m, h.n, p.d, wi);
+            const float w = power_heuristic(lp, bp);
+            add_radiance(img, p.pix, nan_to_zero(w * p.col * li.emit * f * gmax(dot(wi, h.n), 0.f) / lp));
+        }
+    }
+    const f3 offsetDir = dot(s.dir, h.n) > 0 ? h.n : -h.n;
+    p.d = s.dir;
+    p.o = h.p + (isDelta ? 1e-3f * offsetDir : 1e-4f * s.dir);
+    p.col = p.col * (s.bsdf * fabsf(dot(s.dir, h.n)) / s.pdf);
+    if (MODE == PTK_MODE_MIS) p.prevPdf = isDelta ? -1.f : s.pdf;
+    int alive = 1;
+    if (--p.bounces == 0) { p.col = mk3(0.f, 0.f, 0.f); alive = 0; }
+    return alive;
+}
+
+// VIRTUAL = false: thread index is the compacted slot (the reference's launch shape, used by ptk_shade).
+// VIRTUAL = true : paths are still in pre-compaction order; valid_a/agg_a from k_intersect give each hit path its slot.
+template <int MODE, bool VIRTUAL>
+__global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter, int depth, int n_arg, const int* __restrict__ d_n,
+                                                      PtkHits hits, PtkPaths paths, const int* __restrict__ valid_a,
+                                                      const int* __restrict__ agg_a, int* __restrict__ valid_b,
+                                                      int* __restrict__ agg_b, float* __restrict__ img) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * PTK_BLOCK >= n) return;
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    int flag = (i < n) ? 1 : 0;
+    int slot = i;
+    if (VIRTUAL) {
+        flag = (i < n) ? valid_a[i] : 0;
+        int total;
+        const int local = block_excl_prefix(flag, total);
+        slot = prior_blocks(agg_a, b) + local;
+    }
+    int alive = 0;
+    if (flag) {
+        const float4 h0 = ld4(hits.t_n, i), h1 = ld4(hits.p_mat, i), h2 = ld4(hits.uv_ids, i);
+        const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
+        Hit h;
+        h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+        h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
+        PathRegs p;
+        p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+        p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+        p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+        alive = shade_path<MODE>(S, iter, slot, depth, h, p, img);
+        st4(paths.o_pix, i, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+        st4(paths.d_bnc, i, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+        st4(paths.col_pdf, i, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+    }
+    if (i < n) valid_b[i] = alive;
+    if (agg_b) {
+        int total;
+        (void)block_excl_prefix(alive, total);
+        if (threadIdx.x == 0) agg_b[b] = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// compact_rays, pathtrace.cu:614-631: k_count (per-block aggregates) + k_scatter (stable scatter, device count out)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PTK_BLOCK) k_count(int n_arg, const int* __restrict__ d_n, const int* __restrict__ valid, int* __restrict__ agg) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * PTK_BLOCK >= n) return;
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    const int flag = (i < n) ? valid[i] : 0;
+    int total;
+    (void)block_excl_prefix(flag, total);
+    if (threadIdx.x == 0) agg[b] = total;
+}
+
+__global__ void __launch_bounds__(PTK_BLOCK) k_scatter(int n_arg, const int* __restrict__ d_n, const int* __restrict__ valid,
+                                                        const int* __restrict__ agg, PtkPaths pin, PtkHits hin, PtkPaths pout,
+                                                        PtkHits hout, int* __restrict__ count_out) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0 && count_out) *count_out = 0; return; }
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    const int flag = (i < n) ? valid[i] : 0;
+    int total;
+    const int local = block_excl_prefix(flag, total);
+    const int prior = prior_blocks(agg, b);
+    if (flag) {
+        const int s = prior + local;
+        if (pin.o_pix) { st4(pout.o_pix, s, ld4(pin.o_pix, i)); st4(pout.d_bnc, s, ld4(pin.d_bnc, i)); st4(pout.col_pdf, s, ld4(pin.col_pdf, i)); }
+        if (hin.t_n) { st4(hout.t_n, s, ld4(hin.t_n, i)); st4(hout.p_mat, s, ld4(hin.p_mat, i)); st4(hout.uv_ids, s, ld4(hin.uv_ids, i)); }
+    }
+    if (count_out && threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *count_out = prior + total;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sendImageToPBO, pathtrace.cu:32-65 (ACESFilm + gammaCorrection, utilities.h:35-48)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PTK_BLOCK) k_tonemap(const float* __restrict__ img, int P, int iter, uchar4* __restrict__ pbo) {
+    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x = img[3 * (size_t)i + k] / (float)iter;
+        float y = gclamp((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.f, 1.f);
+        y = powf(y, 1 / 2.2f);
+        c[k] = gclamp(y * 255.0f, 0.f, 255.0f);
+    }
+    pbo[i] = make_uchar4((unsigned char)c[0], (unsigned char)c[1], (unsigned char)c[2], 0);
+}
+
+inline int grid_for(int n) { return (n + PTK_BLOCK - 1) / PTK_BLOCK; }
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+inline int launch_rc() { return hip_rc(hipGetLastError()); }
+
+DevCamera to_dev_camera(const PtkCamera& c) {
+    DevCamera d;
+    d.W = c.res[0]; d.H = c.res[1];
+    d.pos = mk3(c.position[0], c.position[1], c.position[2]);
+    d.view = mk3(c.view[0], c.view[1], c.view[2]);
+    d.up = mk3(c.up[0], c.up[1], c.up[2]);
+    d.right = mk3(c.right[0], c.right[1], c.right[2]);
+    d.plx = c.pixelLength[0]; d.ply = c.pixelLength[1];
+    return d;
+}
+
+template <bool V>
+int launch_shade(int mode, const SceneView& S, int iter, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
+                 const int* va, const int* aa, int* vb, int* ab, float* img, hipStream_t st) {
+    const int g = grid_for(n);
+    if (g == 0) return 0;
+    switch (mode) {
+    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    default: return PTK_E_BADARG;
+    }
+    return launch_rc();
+}
+
+// scratch for the stand-alone ptk_compact entry point (per-block aggregates), grown on demand
+int* g_compact_agg = nullptr;
+int g_compact_agg_cap = 0;
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// pipeline-internal launchers
+// ------------------------------------------------------------------------------------------------------------------
+namespace ptk {
+
+int local_path_count(int W, int H, int n_parts, int part, int tile_rows) {
+    if (n_parts <= 1) return W * H;
+    int rows = 0;
+    const int n_tiles = (H + tile_rows - 1) / tile_rows;
+    for (int t = part; t < n_tiles; t += n_parts) rows += std::min(tile_rows, H - t * tile_rows);
+    return rows * W;
+}
+
+int launch_generate(const ::Camera& cam, int iter, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
+                    int n_local, int* d_count0, hipStream_t st) {
+    DevCamera d;
+    d.W = cam.resolution.x; d.H = cam.resolution.y;
+    d.pos = mk3(cam.position.x, cam.position.y, cam.position.z);
+    d.view = mk3(cam.view.x, cam.view.y, cam.view.z);
+    d.up = mk3(cam.up.x, cam.up.y, cam.up.z);
+    d.right = mk3(cam.right.x, cam.right.y, cam.right.z);
+    d.plx = cam.pixelLength.x; d.ply = cam.pixelLength.y;
+    const int g = std::max(1, grid_for(n_local));
+    k_generate<<<g, PTK_BLOCK, 0, st>>>(d, iter, traceDepth, paths, std::max(1, n_parts), part, std::max(1, tile_rows), n_local, d_count0);
+    return launch_rc();
+}
+
+// one bounce of the staged pipeline: intersect -> shade (virtual compaction of misses) -> scatter survivors.
+// `capacity` bounds the launch; the live count is read from ws.counts[depth] on the device.
+static void no_mark(int, bool) {}
+int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
+                                  PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool)) {
+    const int g = grid_for(capacity);
+    if (g == 0) return 0;
+    const int* d_n = ws.counts + depth;
+    mark(1, true);
+    if (ws.stats) k_intersect<true><<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats);
+    else k_intersect<false><<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, nullptr);
+    mark(1, false);
+    int rc = launch_rc(); if (rc) return rc;
+    mark(2, true);
+    rc = launch_shade<true>(mode, S, iter, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, st);
+    mark(2, false);
+    if (rc) return rc;
+    PtkHits none = {nullptr, nullptr, nullptr};
+    mark(3, true);
+    k_scatter<<<g, PTK_BLOCK, 0, st>>>(capacity, d_n, ws.valid_b, ws.agg_b, cur, none, nxt, none, ws.counts + depth + 1);
+    mark(3, false);
+    return launch_rc();
+}
+int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
+                         PtkHits hits, float* img, const Workspace& ws, hipStream_t st) {
+    return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark);
+}
+
+} // namespace ptk
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI: kernel-level entry points (include/ptk.h)
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ptk_generate_rays(const PtkCamera* cam, int iter, int trace_depth, PtkPaths paths, void* stream) {
+    if (!cam || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || cam->res[0] <= 0 || cam->res[1] <= 0) return PTK_E_BADARG;
+    const int n = cam->res[0] * cam->res[1];
+    k_generate<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(to_dev_camera(*cam), iter, trace_depth, paths, 1, 0, 1, n, nullptr);
+    return launch_rc();
+}
+
+int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkHits hits, int* valid,
+                  unsigned long long* stats, void* stream) {
+    if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
+    if (n < 0 || !paths.o_pix || !paths.d_bnc || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid) return PTK_E_BADARG;
+    if (n == 0) return 0;
+    const SceneView S = dev_view(*s->scene);
+    if (stats) k_intersect<true><<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, hits, valid, nullptr, nullptr, stats);
+    else k_intersect<false><<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, hits, valid, nullptr, nullptr, nullptr);
+    return launch_rc();
+}
+
+int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkHits hits_in,
+                PtkPaths paths_out, PtkHits hits_out, int* d_count_out, void* stream) {
+    if (n < 0 || !valid) return PTK_E_BADARG;
+    if (paths_in.o_pix && (!paths_in.d_bnc || !paths_in.col_pdf || !paths_out.o_pix || !paths_out.d_bnc || !paths_out.col_pdf)) return PTK_E_BADARG;
+    if (hits_in.t_n && (!hits_in.p_mat || !hits_in.uv_ids || !hits_out.t_n || !hits_out.p_mat || !hits_out.uv_ids)) return PTK_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = grid_for(n);
+    if (g == 0) { if (d_count_out) return hip_rc(hipMemsetAsync(d_count_out, 0, sizeof(int), st)); return 0; }
+    if (g > g_compact_agg_cap) {
+        if (g_compact_agg) { hipError_t e = hipFree(g_compact_agg); if (e != hipSuccess) return (int)e; }
+        g_compact_agg = nullptr; g_compact_agg_cap = 0;
+        hipError_t e = hipMalloc(&g_compact_agg, sizeof(int) * (size_t)g);
+        if (e != hipSuccess) return (int)e;
+        g_compact_agg_cap = g;
+    }
+    k_count<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg);
+    int rc = launch_rc(); if (rc) return rc;
+    k_scatter<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg, paths_in, hits_in, paths_out, hits_out, d_count_out);
+    return launch_rc();
+}
+
+int ptk_shade(const PtkScene* s, int mode, int iter, int depth, int n, const int* d_n, PtkHits hits,
+              PtkPaths paths, int* valid, float* img, void* stream) {
+    if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
+    if (n < 0 || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid || !img) return PTK_E_BADARG;
+    if (n == 0) return 0;
+    return launch_shade<false>(mode, dev_view(*s->scene), iter, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, (hipStream_t)stream);
+}
+
+int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char* pbo, void* stream) {
+    if (!img || !pbo || res_x <= 0 || res_y <= 0 || iter <= 0) return PTK_E_BADARG;
+    const int P = res_x * res_y;
+    k_tonemap<<<grid_for(P), PTK_BLOCK, 0, (hipStream_t)stream>>>(img, P, iter, reinterpret_cast<uchar4*>(pbo));
+    return launch_rc();
+}
+
+} // extern "C"

@@ -1,0 +1,127 @@
+"""Host scene layer (product C++, through the C ABI) against the oracle's restatement of scene.cpp / BVH.cpp / main.cpp.
+Bit-exact: every table the reference would upload must be identical.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+SCENE_CASES = [
+    ("cornell.txt", None, -1),
+    ("cornell.txt", (400, 400), 4),           # BASELINE config 0
+    ("obj_test.txt", None, -1),               # obsolete-format materials, cube.obj, 0 lights
+    ("mis_test.txt", (1024, 1024), 16),       # BASELINE config 3
+    ("bunny_cornell.txt", None, -1),          # BASELINE config 2 timed scene (10 000 triangles)
+    ("metallic_analytic.txt", None, -1),
+]
+
+
+def _same(a, b, what):
+    assert a.dtype == b.dtype and a.shape == b.shape, what
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        ok = np.array_equal(x, y) if x.dtype.kind != "f" else np.array_equal(x, y, equal_nan=True)
+        assert ok, f"{what}.{name} differs: {np.argwhere(x != y)[:5]}"
+
+
+@pytest.mark.parametrize("name,res,depth", SCENE_CASES)
+def test_scene_tables_match_oracle(ptk, orc, scenes_dir, name, res, depth):
+    path = os.path.join(scenes_dir, name)
+    s = ptk.Scene(path, res=res, depth=depth)
+    o = orc.Scene(path, res=res, depth=depth)
+    assert (s.n_geoms, s.n_materials, s.n_triangles, s.bvh_size, s.n_lights, s.trace_depth, s.iterations, s.width, s.height) == \
+           (o.n_geoms, o.n_materials, o.n_triangles, o.bvh_size, o.n_lights, o.trace_depth, o.iterations, o.width, o.height)
+    _same(s.camera().reshape(1), o.camera().reshape(1), "camera")
+    _same(s.geoms(), o.geoms(), "geoms")
+    _same(s.materials(), o.materials(), "materials")
+    _same(s.triangles(), o.triangles(), "triangles")
+    _same(s.bvh(), o.bvh(), "bvh")
+    _same(s.lights(), o.lights(), "lights")
+    s.close(); o.close()
+
+
+def test_cornell_as_parsed(ptk, scenes_dir):
+    """materials resolve BY NAME first; one cube light; roughness floor 1e-3."""
+    s = ptk.Scene(os.path.join(scenes_dir, "cornell.txt"))
+    assert (s.width, s.height, s.trace_depth, s.iterations) == (800, 800, 8, 5000)
+    assert list(s.geoms()["materialid"]) == [3, 3, 3, 0, 4, 5, 1, 2]
+    assert list(s.geoms()["type"]) == [1, 1, 1, 1, 1, 1, 0, 0]
+    m = s.materials()
+    assert list(m["type"]) == [4, 3, 2, 0, 0, 0, 0, 2, 3]
+    assert m["rough_s"][1] == np.float32(1e-3) and m["rough_s"][8] == np.float32(0.5)
+    assert m["ior"][2] == np.float32(1.6)
+    li = s.lights()
+    assert len(li) == 1 and (li[0]["geomID"], li[0]["triangleID"], li[0]["type"]) == (3, -1, 1)
+    assert s.n_triangles == 0 and s.bvh_size == 1          # one empty root node per direction
+    cam = s.camera()
+    # SURVEY §8a K1 [probe]
+    assert np.allclose(cam["view"], [-4.37113883e-08, 0, -1], rtol=0, atol=1e-15)
+    assert np.allclose(cam["right"], [1, 0, -4.37113883e-08], rtol=0, atol=1e-15)
+    assert list(cam["up"]) == [0, 1, 0]
+    assert cam["pixelLength"][0] == np.float32(0.00249999994)
+
+
+def test_obj_test_obsolete_format(ptk, scenes_dir):
+    """obj_test.txt's RGB/SPECEX/... lines are unrecognised -> 5 default materials, 0 lights, cube.obj."""
+    s = ptk.Scene(os.path.join(scenes_dir, "obj_test.txt"))
+    m = s.materials()
+    assert len(m) == 5 and (m["type"] == 0).all() and (m["albedo"] == 1).all() and (m["albedo_s"] == 0).all()
+    assert s.n_lights == 0 and s.n_triangles == 12 and s.bvh_size == 23
+    b = s.bvh()
+    # SURVEY §8a H3 [probe], direction 0
+    exp = [(0, 12, 1, -1), (0, 2, 2, 4), (0, 1, 3, 3), (1, 2, 4, 4), (2, 12, 5, -1), (2, 4, 6, 8)]
+    for i, (st, en, hit, miss) in enumerate(exp):
+        assert (b[i]["start"], b[i]["end"], b[i]["hit"], b[i]["miss"]) == (st, en, hit, miss), i
+    assert list(b[0]["pMin"]) == [-2, 4, -1] and list(b[0]["pMax"]) == [-1, 5, 0]
+
+
+def test_bvh_structure_invariants(ptk, scenes_dir):
+    """Every triangle sits in exactly one leaf; each direction's hit/miss threading visits every leaf exactly once
+    when no box is culled (follow `hit` only), and `miss` always skips exactly the node's subtree."""
+    s = ptk.Scene(os.path.join(scenes_dir, "bunny_cornell.txt"))
+    B = s.bvh_size
+    b = s.bvh().reshape(6, B)
+    assert s.n_triangles == 10000 and B == 2 * 10000 - 1
+    leaves = (b[0]["end"] - b[0]["start"]) <= 1
+    covered = np.zeros(s.n_triangles, np.int32)
+    for st, en in zip(b[0]["start"][leaves], b[0]["end"][leaves]):
+        covered[st:en] += 1
+    assert (covered == 1).all()
+    for d in range(6):
+        seen = np.zeros(B, bool); i = 0; steps = 0
+        while i != -1:
+            assert not seen[i]; seen[i] = True; i = int(b[d]["hit"][i]); steps += 1
+        assert steps == B and seen.all()
+        # preorder layout: the subtree of node i is [i, i + 2*count - 1); miss must leave it
+        cnt = b[d]["end"] - b[d]["start"]
+        size = np.where(cnt <= 1, 1, 2 * cnt - 1)
+        miss = b[d]["miss"]
+        inside = (miss >= np.arange(B)) & (miss < np.arange(B) + size)
+        assert not inside[miss != -1].any()
+
+
+def test_errors(ptk, scenes_dir, tmp_path):
+    with pytest.raises(ptk.PtkError) as e:
+        ptk.Scene(os.path.join(scenes_dir, "does_not_exist.txt"))
+    assert e.value.code == ptk.E_PARSE
+    bad = tmp_path / "tex.txt"
+    bad.write_text("MATERIAL a\nTYPE Lambertian\nALBEDO ../scenes/texture/foo.png\n\nCAMERA\nRES 8 8\nFOVY 45\nITERATIONS 1\nDEPTH 2\nFILE x\nEYE 0 0 1\nLOOKAT 0 0 0\nUP 0 1 0\n")
+    with pytest.raises(ptk.PtkError):
+        ptk.Scene(str(bad))
+    # empty / comment-only file parses to an empty scene; rendering it is refused
+    empty = tmp_path / "empty.txt"
+    empty.write_text("// nothing\n")
+    with pytest.raises(ptk.PtkError):
+        ptk.Scene(str(empty)).upload()   # no GPU here -> E_NODEVICE; on a GPU box: no camera -> init would fail
+
+
+def test_crlf_and_name_lookup(ptk, tmp_path):
+    """\\r\\n line ends are accepted (safeGetline) and `material <x>` resolves by name before atoi (scene.cpp:124-131)."""
+    txt = ("MATERIAL 1\r\nTYPE Light\r\nALBEDO 3 3 3\r\n\r\nMATERIAL 0\r\nTYPE Lambertian\r\nALBEDO .5 .5 .5\r\n\r\n"
+           "CAMERA\r\nRES 16 8\r\nFOVY 30\r\nITERATIONS 2\r\nDEPTH 3\r\nFILE t\r\nEYE 0 1 5\r\nLOOKAT 0 1 0\r\nUP 0 1 0\r\n\r\n"
+           "OBJECT a\r\nsphere\r\nmaterial 1\r\nTRANS 0 1 0\r\nROTAT 0 0 0\r\nSCALE 1 1 1\r\n\r\n"
+           "OBJECT b\r\ncube\r\nmaterial 0\r\nTRANS 0 0 0\r\nROTAT 0 45 0\r\nSCALE 4 .1 4\r\n")
+    f = tmp_path / "crlf.txt"; f.write_bytes(txt.encode())
+    s = ptk.Scene(str(f))
+    assert (s.width, s.height, s.trace_depth) == (16, 8, 3)
+    assert list(s.geoms()["materialid"]) == [0, 1]        # name "1" is material index 0, name "0" is index 1
+    assert s.n_lights == 1 and s.lights()[0]["type"] == 0
