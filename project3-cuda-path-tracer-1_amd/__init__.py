@@ -80,10 +80,25 @@ CAMERA_DT = np.dtype([("res", "<i4", 2), ("position", "<f4", 3), ("lookAt", "<f4
                       ("right", "<f4", 3), ("fov", "<f4", 2), ("pixelLength", "<f4", 2)])
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  Two HIP runtimes in one process cannot share stream handles,
+    so make torch's copy the one libptk.so binds to: load it (by file) before libptk.so, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the HIP path)")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, ci = C.c_void_p, C.c_int
     lib.ptk_scene_load.argtypes = [C.c_char_p, ci, ci, ci, C.POINTER(vp)]

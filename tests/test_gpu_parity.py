@@ -138,7 +138,7 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
     r.close()
     bad = (img != ref).any(axis=1)
     assert not bad.any(), f"{int(bad.sum())} of {len(ref)} pixels differ; first {np.argwhere(bad)[:3].ravel()}"
-    if name != "obj_test.txt":
+    if name != "obj_test.txt" and not (name == "cornell.txt" and mode == "DIRECT"):   # cube light: direct lighting is black by construction
         assert ref.sum() > 0
 
 
