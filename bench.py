@@ -131,22 +131,27 @@ def main():
         q = torch.tensor([rays], dtype=torch.int64, device="cuda"); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
 
     # ---- untimed: per-kernel device time (HIP events on the render stream) + traversal statistics ----
-    r.traversal_stats(enable=True)
     r.profile_begin()
     rays_p0 = r.ray_total()
     for _ in range(a.profile_steps):
         it += 1; r.iterate(it)
     prof = r.profile_end()
     rays_p = r.ray_total() - rays_p0
-    nodes, tris = r.traversal_stats()
-    r.traversal_stats(enable=False)
     counts, traced = r.live_counts()
+    nodes = tris = rays_s = 0
+    if scene.n_triangles > 0:          # BVH scenes: mean node visits / triangle tests per ray (instrumented kernel, separate pass)
+        r.traversal_stats(enable=True)
+        rays_s0 = r.ray_total()
+        it += 1; r.iterate(it)
+        nodes, tris = r.traversal_stats()
+        rays_s = r.ray_total() - rays_s0
+        r.traversal_stats(enable=False)
     r.close()
 
     if rank == 0:
         ms_int, n_int = prof["intersect"]
         has_bvh = scene.n_triangles > 0
-        bytes_per_ray = BYTES_PER_RAY_ANALYTIC + (BYTES_PER_NODE * nodes / max(rays_p, 1) + BYTES_PER_TRI * tris / max(rays_p, 1) if has_bvh else 0.0)
+        bytes_per_ray = BYTES_PER_RAY_ANALYTIC + (BYTES_PER_NODE * nodes / max(rays_s, 1) + BYTES_PER_TRI * tris / max(rays_s, 1) if has_bvh else 0.0)
         achieved = rays_p * bytes_per_ray / (ms_int * 1e-3) / 1e9 if ms_int > 0 else 0.0
         live_launches = int((counts > 0).sum())         # launches that had paths to process, per iteration
         roofline = {
@@ -154,6 +159,7 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / max(a.profile_steps * max(live_launches, 1), 1), 1),
             "avg_launch_us": round(1e3 * ms_int / max(a.profile_steps * max(live_launches, 1), 1), 2),
+            "nodes_per_ray": round(nodes / max(rays_s, 1), 3) if has_bvh else 0, "tris_per_ray": round(tris / max(rays_s, 1), 3) if has_bvh else 0,
             "note": "device time of k_intersect from HIP events on the render stream over %d untimed iterations; launches with zero live "
                     "paths excluded from the average; per-kernel split ms/iter: %s" % (
                         a.profile_steps, {k: round(v[0] / a.profile_steps, 4) for k, v in prof.items()}),
