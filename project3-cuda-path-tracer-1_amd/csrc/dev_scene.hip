@@ -43,6 +43,10 @@ int DevScene::initiate(Scene& scene) {
         rows3x4(s.inverseTransform, g[i].inv);
         rows3x4(s.transform, g[i].fwd);
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[i].invT[r * 3 + c] = s.invTranspose.at(c, r);
+        bool diag = true;                       // all off-diagonal 3x3 entries exactly +-0 (e.g. ROTAT 0 0 0)
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+            if (r != c && (s.inverseTransform.at(c, r) != 0.f || s.transform.at(c, r) != 0.f || s.invTranspose.at(c, r) != 0.f)) diag = false;
+        g[i].diag = diag ? 1 : 0;
     }
     std::vector<DevMaterial> m(scene.materials.size());
     for (size_t i = 0; i < m.size(); ++i) {

@@ -106,7 +106,7 @@ struct DevGeom {
     float inv[12];      // inverseTransform rows 0..2
     float fwd[12];      // transform rows 0..2
     float invT[9];      // upper 3x3 of invTranspose, row-major
-    float pad;
+    int diag;           // 1: the 3x3 parts of inv, fwd and invT are diagonal (all off-diagonal entries are +-0)
 };
 struct DevMaterial {    // 12 dwords
     int type;
@@ -131,6 +131,24 @@ struct SceneView {
     const DevLight* lights;      int n_lights;
 };
 
+// Wave-uniform load of one primitive record into SGPRs.  The scene tables are immutable while a kernel runs, but the
+// compiler cannot prove that for a pointer inside a by-value struct, and then falls back to VECTOR loads of uniform
+// addresses (33 global_load_dword per primitive per wave).  Reading through the constant address space (4) makes it
+// emit s_load_dwordx8/x16 instead, and the matrices become scalar operands of the VALU instructions.
+PTK_DI DevGeom load_geom_uniform(const DevGeom* base, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t __attribute__((address_space(4)))* cptr;
+    cptr p = (cptr)(const uint32_t*)(base + i);
+    DevGeom g;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&g);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(DevGeom) / 4); ++k) dst[k] = p[k];
+    return g;
+#else
+    return base[i];
+#endif
+}
+
 // vec3(M * vec4(v,1)) and vec3(M * vec4(v,0)) in glm's order (type_mat4x4.inl:617-628)
 PTK_DI f3 xform_point(const float* m, f3 v) {
     return mk3((m[0] * v.x + m[1] * v.y) + (m[2] * v.z + m[3]),
@@ -148,11 +166,29 @@ PTK_DI f3 xform_nrm(const float* m, f3 v) {
                (m[6] * v.x + m[7] * v.y) + (m[8] * v.z));
 }
 
+// Diagonal fast paths.  With exactly-zero off-diagonal entries, (m0*x + 0*y) + (0*z + m3) == m0*x + m3 and
+// (m0*x + 0*y) + 0*z == m0*x for finite x,y,z (adding +-0 changes at most the sign of a zero), so these return values
+// that compare == to the general forms above.  `diag` is wave-uniform (it comes from the SGPR-resident geom record).
+PTK_DI f3 xform_point_d(const float* m, f3 v, int diag) {
+    if (diag) return mk3(m[0] * v.x + m[3], m[5] * v.y + m[7], m[10] * v.z + m[11]);
+    return xform_point(m, v);
+}
+PTK_DI f3 xform_dir_d(const float* m, f3 v, int diag) {
+    if (diag) return mk3(m[0] * v.x, m[5] * v.y, m[10] * v.z);
+    return xform_dir(m, v);
+}
+PTK_DI f3 xform_nrm_d(const float* m, f3 v, int diag) {
+    if (diag) return mk3(m[0] * v.x, m[4] * v.y, m[8] * v.z);
+    return xform_nrm(m, v);
+}
+
 // ---- primitives -----------------------------------------------------------------------------------
 // boxIntersectionTest, intersections.h:48-90.  Returns world-space distance or -1.
-PTK_DI float box_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& N) {
-    f3 qo = xform_point(g.inv, ro);
-    f3 qd = normalize(xform_dir(g.inv, rd));
+// The normal is NOT computed here: `ns` receives the object-space vector n with N = normalize(invTranspose * n), so the
+// caller evaluates it once for the primitive that wins (the reference evaluates it for every candidate and discards it).
+PTK_DI float box_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& ns) {
+    f3 qo = xform_point_d(g.inv, ro, g.diag);
+    f3 qd = normalize(xform_dir_d(g.inv, rd, g.diag));
     float tmin = -1e38f, tmax = 1e38f;
     int amin = 0, amax = 0; float smin = 0.f, smax_ = 0.f;     // normal = axis * sign (zero-initialised tmin_n/tmax_n)
 #pragma unroll
@@ -167,19 +203,18 @@ PTK_DI float box_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& N) {
     }
     if (tmax >= tmin && tmax > 0) {
         if (tmin <= 0) { tmin = tmax; amin = amax; smin = smax_; }
-        f3 n = mk3(amin == 0 ? smin : 0.f, amin == 1 ? smin : 0.f, amin == 2 ? smin : 0.f);
+        ns = mk3(amin == 0 ? smin : 0.f, amin == 1 ? smin : 0.f, amin == 2 ? smin : 0.f);
         f3 p = qo + (tmin - .0001f) * normalize(qd);                       // getPointOnRay, intersections.h:27-29
-        P = xform_point(g.fwd, p);
-        N = normalize(xform_nrm(g.invT, n));
+        P = xform_point_d(g.fwd, p, g.diag);
         return length(ro - P);
     }
     return -1.f;
 }
 
-// sphereIntersectionTest, intersections.h:102-144
-PTK_DI float sphere_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& N) {
-    f3 o = xform_point(g.inv, ro);
-    f3 d = normalize(xform_dir(g.inv, rd));
+// sphereIntersectionTest, intersections.h:102-144 (normal deferred like box_test: ns = object-space hit point)
+PTK_DI float sphere_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& ns) {
+    f3 o = xform_point_d(g.inv, ro, g.diag);
+    f3 d = normalize(xform_dir_d(g.inv, rd, g.diag));
     float vd = dot(o, d);
     float radicand = vd * vd - (dot(o, o) - 0.25f);
     if (radicand < 0) return -1.f;
@@ -191,10 +226,12 @@ PTK_DI float sphere_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& N) {
     else if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
     else t = (t1 < t2) ? t2 : t1;
     f3 obj = o + (t - .0001f) * normalize(d);
-    P = xform_point(g.fwd, obj);
-    N = normalize(xform_nrm(g.invT, obj));
+    P = xform_point_d(g.fwd, obj, g.diag);
+    ns = obj;
     return length(ro - P);
 }
+// the deferred normal of an analytic primitive: normalize(invTranspose * ns)  (intersections.h:87, 138)
+PTK_DI f3 analytic_normal(const DevGeom& g, f3 ns) { return normalize(xform_nrm_d(g.invT, ns, g.diag)); }
 
 // Bounds3::IntersectP(ray, t), Bounds3.hpp:162-189
 PTK_DI bool aabb_test(const DevNode& nd, f3 o, f3 d, f3 inv, float& t) {
@@ -254,15 +291,15 @@ template <bool STATS>
 PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
     float t_min = FLT_MAX;
     int hit_geom = -1, tri_id = -1;
-    f3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
+    f3 P = mk3(0, 0, 0), N = mk3(0, 0, 0), NS = mk3(0, 0, 0);
     float bu = 0.f, bv = 0.f;
     float t = -1.f;
     for (int i = 0; i < S.n_geoms; ++i) {                       // wave-uniform loop: geom record lives in SGPRs
-        const DevGeom& g = S.geoms[i];
+        const DevGeom g = load_geom_uniform(S.geoms, i);
         f3 tp, tn;
         if (g.type == 1) t = box_test(g, ro, rd, tp, tn);
         else if (g.type == 0) t = sphere_test(g, ro, rd, tp, tn);
-        if (t > 0.0f && t_min > t) { t_min = t; hit_geom = i; P = tp; N = tn; }
+        if (t > 0.0f && t_min > t) { t_min = t; hit_geom = i; P = tp; NS = tn; }
     }
     // threaded (stackless) BVH walk over the direction-ordered links (pathtrace.cu:236-279)
     const int2* links = S.links + (size_t)mtbvh_dir(rd) * S.bvh_size;
@@ -294,6 +331,7 @@ PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeV
         h.uv.y = gclamp(w * A.t0[1] + bu * A.t1[1] + bv * A.t2[1], 0.f, 1.f);
     } else {
         h.uv.x = 0.f; h.uv.y = 0.f;
+        if (hit_geom >= 0) N = analytic_normal(S.geoms[hit_geom], NS);      // per-lane geom index: one gather, once per ray
     }
     if (hit_geom == -1) { h.t = -1.0f; return 0; }
     h.t = t_min; h.p = P; h.n = normalize(N);
@@ -306,7 +344,7 @@ PTK_DI bool occluded(const SceneView& S, f3 ori, f3 dir, f3 des) {
     float minT = length(des - ori);
     float t = 0.f;
     for (int i = 0; i < S.n_geoms; ++i) {
-        const DevGeom& g = S.geoms[i];
+        const DevGeom g = load_geom_uniform(S.geoms, i);
         f3 tp, tn;
         if (g.type == 1) t = box_test(g, ori, dir, tp, tn);
         else if (g.type == 0) t = sphere_test(g, ori, dir, tp, tn);
