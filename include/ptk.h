@@ -159,6 +159,9 @@ int ptk_get_ray_total(unsigned long long* rays);
 /* Restrict rendering to the pixels of interleaved tiles: pixel (x,y) is traced iff
  * ((y / tile_rows) % n_parts) == part.  (1,0,*) = whole frame.  Multi-GPU sharding, SURVEY §8e. */
 int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
+/* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
+int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
+int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
 /* Pipeline selection: 0 = staged kernels (reference order), reserved values for fused variants. */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);

@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
+    "ptk_partition_count", "ptk_partition_pixel",
 ]
 
 
@@ -190,6 +191,15 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def partition_pixels(W: int, H: int, n_parts: int, part: int, tile_rows: int) -> np.ndarray:
+    """Pixel indices (x + y*W) owned by `part`, in the order its paths are generated (host-only helper)."""
+    n = lib.ptk_partition_count(W, H, n_parts, part, tile_rows)
+    if n < 0:
+        raise PtkError("ptk_partition_count", E_BADARG)
+    return np.array([lib.ptk_partition_pixel(W, n_parts, part, tile_rows, j) for j in range(0, n, W)], np.int64)[:, None].repeat(W, 1) \
+        + np.arange(W, dtype=np.int64)[None, :] if n else np.zeros((0, W), np.int64)
 
 
 # ---------------------------------------------------------------------------------------------

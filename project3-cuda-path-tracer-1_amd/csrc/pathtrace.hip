@@ -198,6 +198,18 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows) {
     g.n_parts = n_parts; g.part = part; g.tile_rows = tile_rows;
     return 0;
 }
+/* Host-only helpers describing the tile partition (no GPU needed): number of paths rank `part` owns, and the pixel index
+ * (x + y*W) that local path j maps to — the same mapping k_generate uses. */
+int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows) {
+    if (W < 1 || H < 1 || n_parts < 1 || part < 0 || part >= n_parts || tile_rows < 1) return -1;
+    return local_path_count(W, H, n_parts, part, tile_rows);
+}
+int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
+    if (W < 1 || n_parts < 1 || part < 0 || part >= n_parts || tile_rows < 1 || j < 0) return -1;
+    const int lr = j / W, x = j - lr * W;
+    const int y = ((lr / tile_rows) * n_parts + part) * tile_rows + (lr % tile_rows);
+    return x + y * W;
+}
 int ptk_set_pipeline(int which) { if (which != 0) return PTK_E_BADARG; g.pipeline = which; return 0; }
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the
  * render stream; end -> synchronises and returns, per kernel class (0 generate, 1 intersect, 2 shade, 3 scatter),

@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: two gloo ranks use the library's host-side tile partition (the mapping k_generate uses) to own
+disjoint pixel sets, render a synthetic per-pixel function into a full-frame buffer, and reduce it to rank 0 exactly the
+way bench.py does with RCCL (one SUM reduce of float32[3*W*H], MAX of the elapsed time, SUM of the ray counts)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _pixel_value(pix):
+    return np.stack([np.sin(pix * 0.01) + 2, (pix % 97) / 97.0, pix * 1e-4], 1).astype(np.float32)
+
+
+def _worker(rank, world, port, W, H, rows, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
+    mine = ptk.partition_pixels(W, H, world, rank, rows).ravel()
+    assert len(mine) == ptk.lib.ptk_partition_count(W, H, world, rank, rows)
+    img = np.zeros((W * H, 3), np.float32)
+    img[mine] = _pixel_value(mine)                       # zeros outside the rank's own tiles
+    t = torch.from_numpy(img)
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+    el = torch.tensor([1.0 + rank], dtype=torch.float64); dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    rays = torch.tensor([len(mine)], dtype=torch.int64); dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    owners = torch.zeros(W * H, dtype=torch.int32); owners[torch.from_numpy(mine)] = 1
+    dist.all_reduce(owners, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "img.npy"), t.numpy())
+        np.save(os.path.join(out_dir, "meta.npy"), np.array([el.item(), rays.item(), owners.min().item(), owners.max().item()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H,rows", [(40, 37, 8), (16, 5, 1), (33, 64, 16)])
+def test_two_rank_tile_reduce(tmp_path, ptk, W, H, rows):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), W, H, rows, str(tmp_path)), nprocs=world, join=True)
+    img = np.load(tmp_path / "img.npy"); meta = np.load(tmp_path / "meta.npy")
+    pix = np.arange(W * H)
+    assert np.array_equal(img, _pixel_value(pix))         # disjoint supports: the SUM reduce reassembles the frame exactly
+    assert meta[0] == 2.0 and meta[1] == W * H             # MAX over ranks of the time, SUM of the units
+    assert meta[2] == 1 and meta[3] == 1                   # every pixel owned by exactly one rank
+
+
+def test_partition_matches_definition(ptk):
+    """pixel (x,y) belongs to part ((y // rows) % n); paths are enumerated row-major over the owned rows."""
+    for W, H, n, rows in ((7, 23, 3, 4), (5, 9, 8, 2), (4, 4, 1, 1)):
+        seen = np.zeros(W * H, np.int32)
+        for part in range(n):
+            pix = ptk.partition_pixels(W, H, n, part, rows).ravel()
+            ys = pix // W
+            assert (((ys // rows) % n) == part).all()
+            assert (np.diff(pix) > 0).all()
+            seen[pix] += 1
+        assert (seen == 1).all()
+    assert ptk.lib.ptk_partition_count(8, 8, 2, 2, 1) == -1
