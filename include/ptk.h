@@ -162,7 +162,9 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 /* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
-/* Pipeline selection: 0 = staged kernels (reference order), reserved values for fused variants. */
+/* Pipeline selection: 0 = staged kernels, BVH walked inside the intersect kernel, one ray per lane (default);
+ * 1 = staged kernels, BVH walked by a separate kernel over a work list of the rays that enter the root box (A/B comparison;
+ *     measured slower on MI355X: the contended list-append atomic costs more than the denser waves save). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 

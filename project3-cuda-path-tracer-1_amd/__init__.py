@@ -256,9 +256,10 @@ def tonemap(img, w: int, h: int, it: int, pbo):
 class Renderer:
     """File-static render context of the library (one at a time, like the reference)."""
 
-    def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1)):
+    def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1), pipeline: int = 0):
         self.scene = scene
         lib.ptk_pathtrace_free()
+        _chk(lib.ptk_set_pipeline(pipeline), "ptk_set_pipeline")
         _chk(lib.ptk_set_tile_partition(*partition), "ptk_set_tile_partition")
         _chk(lib.ptk_set_sample_mode(mode), "ptk_set_sample_mode")
         if not scene.uploaded:

@@ -4,11 +4,11 @@
 // HBM layout (all read-only during rendering, replicated per GPU; a few MB at most):
 //   DevGeom[G]      144 B each : analytic primitives, matrices as 3x4 rows  -> read through scalar loads
 //   DevMaterial[M]   48 B each : constant BSDF parameters (roughness/metallic pre-clamped)
-//   DevNode[B]       32 B each : AABB + primitive range, ONE copy shared by the six traversal directions
-//   int2[6][B]        8 B each : (hit, miss) links of the six direction-ordered threaded BVHs
-//   DevTriV[T]       36 B each : world-space vertex positions (what traversal touches)
+//   DevNode[6][B]    32 B each : AABB + the two links of one direction-ordered threaded BVH, leaf/triangle folded into the
+//                                link words (two 16-B loads per node visit; the reference's GpuBVHNode is 40 B)
+//   DevTriE[T]       48 B each : v0 + the two edges (what a triangle test touches; the reference copies 124 B)
+//   DevTriV[T]       36 B each : vertex positions (attribute interpolation of the final hit, light sampling)
 //   DevTriA[T]       64 B each : vertex normals, texcoords, geomIdx (touched once per ray, for the final hit)
-// The reference uploads 6 full 40-byte node copies (240 B per node) and 124-byte triangles; this is 80 B per node.
 #include "ptk_internal.h"
 #include <cstring>
 
@@ -60,20 +60,26 @@ int DevScene::initiate(Scene& scene) {
         m[i].ior = s.ior;
     }
     const int B = scene.bvhSize;
-    std::vector<DevNode> nodes(B);
-    std::vector<int2> links((size_t)6 * B);
-    for (int i = 0; i < B; ++i) {
+    std::vector<DevNode> nodes((size_t)6 * B);
+    for (size_t i = 0; i < nodes.size(); ++i) {
         const GpuBVHNode& n = scene.gpuBVHNodes[i];
-        nodes[i] = DevNode{n.pMin.x, n.pMin.y, n.pMin.z, n.pMax.x, n.pMax.y, n.pMax.z, n.start, n.end};
+        DevNode o{n.pMin.x, n.pMin.y, n.pMin.z, n.pMax.x, n.pMax.y, n.pMax.z, 0, 0};
+        if (n.end - n.start <= 1) {                 // leaf (MAX_PRIM = 1): hit link == miss link by construction (BVH.cpp:200-236)
+            if (n.hit != n.miss) return PTK_E_BADARG;
+            o.a = n.end > n.start ? -(n.start + 2) : -1;
+            o.b = n.hit;
+        } else { o.a = n.hit; o.b = n.miss; }
+        nodes[i] = o;
     }
-    for (int d = 0; d < 6; ++d)
-        for (int i = 0; i < B; ++i) { const GpuBVHNode& n = scene.gpuBVHNodes[(size_t)d * B + i]; links[(size_t)d * B + i] = make_int2(n.hit, n.miss); }
+    std::vector<DevTriE> te(scene.triangles.size());
     std::vector<DevTriV> tv(scene.triangles.size());
     std::vector<DevTriA> ta(scene.triangles.size());
     for (size_t i = 0; i < tv.size(); ++i) {
         const Triangle& t = scene.triangles[i];
         const ptk::vec3* v = t.v; const ptk::vec3* n = t.n;
         tv[i] = DevTriV{{v[0].x, v[0].y, v[0].z}, {v[1].x, v[1].y, v[1].z}, {v[2].x, v[2].y, v[2].z}};
+        te[i] = DevTriE{{v[0].x, v[0].y, v[0].z}, {v[1].x - v[0].x, v[1].y - v[0].y, v[1].z - v[0].z},
+                        {v[2].x - v[0].x, v[2].y - v[0].y, v[2].z - v[0].z}, {0.f, 0.f, 0.f}};
         ta[i] = DevTriA{{n[0].x, n[0].y, n[0].z}, {n[1].x, n[1].y, n[1].z}, {n[2].x, n[2].y, n[2].z},
                         {t.tex[0].x, t.tex[0].y}, {t.tex[1].x, t.tex[1].y}, {t.tex[2].x, t.tex[2].y}, t.geomIdx};
     }
@@ -84,7 +90,7 @@ int DevScene::initiate(Scene& scene) {
     if ((rc = upload(&dev_geoms, g))) return rc;
     if ((rc = upload(&dev_materials, m))) return rc;
     if ((rc = upload(&dev_nodes, nodes))) return rc;
-    if ((rc = upload(&dev_links, links))) return rc;
+    if ((rc = upload(&dev_trie, te))) return rc;
     if ((rc = upload(&dev_triv, tv))) return rc;
     if ((rc = upload(&dev_tria, ta))) return rc;
     if ((rc = upload(&dev_lights, li))) return rc;
@@ -94,7 +100,7 @@ int DevScene::initiate(Scene& scene) {
 }
 
 void DevScene::destroy() {
-    void** ptrs[] = {&dev_geoms, &dev_materials, &dev_nodes, &dev_links, &dev_triv, &dev_tria, &dev_lights};
+    void** ptrs[] = {&dev_geoms, &dev_materials, &dev_nodes, &dev_trie, &dev_triv, &dev_tria, &dev_lights};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     uploaded = false;
 }

@@ -55,7 +55,7 @@ int context_free() {
     free_paths(g.bufA); free_paths(g.bufB);
     dfree(g.hits.t_n); dfree(g.hits.p_mat); dfree(g.hits.uv_ids);
     dfree(g.ws.agg_a); dfree(g.ws.agg_b); dfree(g.ws.valid_a); dfree(g.ws.valid_b);
-    dfree(g.ws.counts); dfree(g.ws.ray_total); dfree(g.ws.stats);
+    dfree(g.ws.counts); dfree(g.ws.ray_total); dfree(g.ws.stats); dfree(g.ws.queue); dfree(g.ws.list);
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
     if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
@@ -92,6 +92,10 @@ int context_init(Scene* scene) {
     if ((rc = dalloc(&g.ws.valid_b, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&g.ws.counts, (size_t)g.traceDepth + 2))) return rc;
     if ((rc = dalloc(&g.ws.ray_total, 1))) return rc;
+    if ((rc = dalloc(&g.ws.queue, 1))) return rc;
+    if ((rc = dalloc(&g.ws.list, (size_t)g.capacity))) return rc;
+    if ((e = hipMemsetAsync(g.ws.queue, 0, sizeof(unsigned), g.stream)) != hipSuccess) return (int)e;
+    g.ws.inline_bvh = (g.pipeline == 0);
     if ((e = hipMemsetAsync(g.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), g.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(g.ws.ray_total, 0, sizeof(unsigned long long), g.stream)) != hipSuccess) return (int)e;
     g.ws.capacity = g.capacity;
@@ -210,7 +214,11 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     const int y = ((lr / tile_rows) * n_parts + part) * tile_rows + (lr % tile_rows);
     return x + y * W;
 }
-int ptk_set_pipeline(int which) { if (which != 0) return PTK_E_BADARG; g.pipeline = which; return 0; }
+int ptk_set_pipeline(int which) {
+    if (which != 0 && which != 1) return PTK_E_BADARG;
+    g.pipeline = which; g.ws.inline_bvh = (which == 0);
+    return 0;
+}
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the
  * render stream; end -> synchronises and returns, per kernel class (0 generate, 1 intersect, 2 shade, 3 scatter),
  * the summed device time in ms and the number of launches.  Not for use inside a timed region. */

@@ -114,19 +114,24 @@ struct DevMaterial {    // 12 dwords
     float rough, metal, ior;     // rough/metal already clamped like Material::BSDF does (material.h:486-487)
     float pad[2];
 };
-struct DevNode {        // 32 B: AABB + primitive range (shared by the 6 directions)
+// One node of a direction-ordered threaded BVH, 32 B = two 16-B loads.  a/b encode the reference's (start,end,hit,miss):
+//   a >=  0 : inner node, a = hit link (first child in this direction's order), b = miss link
+//   a == -1 : empty leaf (start == end; only the root of a triangle-free scene), b = next (hit == miss for leaves)
+//   a <= -2 : leaf holding triangle -(a + 2)  (MAX_PRIM = 1, BVH.h:5), b = next
+struct DevNode {
     float minx, miny, minz, maxx, maxy, maxz;
-    int start, end;
+    int a, b;
 };
-struct DevTriV { float v0[3], v1[3], v2[3]; };                                  // 36 B, positions only (traversal)
+struct DevTriE { float v0[3], e1[3], e2[3], pad[3]; };                          // 48 B: v0 and the two edges (e = v - v0 as in Bounds3.hpp:300-301)
+struct DevTriV { float v0[3], v1[3], v2[3]; };                                  // 36 B, positions (attribute interpolation, light sampling)
 struct DevTriA { float n0[3], n1[3], n2[3]; float t0[2], t1[2], t2[2]; int geomIdx; };  // 64 B, shading attributes
 struct DevLight { int geomID, triangleID, type; };
 
 struct SceneView {
     const DevGeom* geoms;        int n_geoms;
     const DevMaterial* mats;     int n_mats;
-    const DevNode* nodes;        int bvh_size;
-    const int2* links;           // [6][bvh_size] (hit, miss)
+    const DevNode* nodes;        int bvh_size;   // [6][bvh_size]
+    const DevTriE* trie;         // traversal form of the triangles
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;
 };
@@ -258,11 +263,25 @@ PTK_DI bool aabb_test(const DevNode& nd, f3 o, f3 d, f3 inv, float& t) {
     return tEnter <= tExit && tExit > 0;
 }
 
-// Triangle::getInterSect, Bounds3.hpp:298-326
-PTK_DI bool tri_test(const DevTriV& T, f3 o, f3 d, float& t, float& u, float& v) {
+// Same test for a ray with no zero direction component (the common case), ~23 VALU instead of ~50.  With d_k != 0 the
+// reference's "swap if d_k < 0" equals min/max of the two plane distances (boxes of a non-empty BVH have min <= max), and no
+// NaN can arise ((plane - o) is finite or +-inf, inv is finite and non-zero), so compare-and-select chains equal min/max.
+// The -FLT_MAX / FLT_MAX seeds are kept so that every comparison the caller makes sees the same values.
+PTK_DI bool aabb_test_fast(const DevNode& nd, f3 o, f3 inv, float& t) {
+    const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
+    const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
+    const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
+    const float tEnter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), -FLT_MAX));
+    const float tExit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), FLT_MAX));
+    t = tEnter;
+    return tEnter <= tExit && tExit > 0;
+}
+
+// Triangle::getInterSect, Bounds3.hpp:298-326 (e1, e2 are the same fp32 subtractions, done once on the host)
+PTK_DI bool tri_test(const DevTriE& T, f3 o, f3 d, float& t, float& u, float& v) {
     f3 v0 = mk3(T.v0[0], T.v0[1], T.v0[2]);
-    f3 e1 = mk3(T.v1[0], T.v1[1], T.v1[2]) - v0;
-    f3 e2 = mk3(T.v2[0], T.v2[1], T.v2[2]) - v0;
+    f3 e1 = mk3(T.e1[0], T.e1[1], T.e1[2]);
+    f3 e2 = mk3(T.e2[0], T.e2[1], T.e2[2]);
     f3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
     if (det == 0) return false;
@@ -286,56 +305,83 @@ struct Hit {
     float t; f3 n; f3 p; f2 uv; int mat, geom, tri;
 };
 
-// computeIntersections body (pathtrace.cu:191-343) for one ray.  Returns rayValid.
-template <bool STATS>
-PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
-    float t_min = FLT_MAX;
-    int hit_geom = -1, tri_id = -1;
-    f3 P = mk3(0, 0, 0), N = mk3(0, 0, 0), NS = mk3(0, 0, 0);
-    float bu = 0.f, bv = 0.f;
+// ---- closest hit, in three pieces so that kernels can schedule them differently -----------------------------------
+// (1) analytic primitives (pathtrace.cu:211-235): wave-uniform loop, primitive records in SGPRs
+struct Analytic { float t_min; int geom; f3 P, NS; };
+PTK_DI void analytic_closest(const SceneView& S, f3 ro, f3 rd, Analytic& a) {
+    a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0);
     float t = -1.f;
-    for (int i = 0; i < S.n_geoms; ++i) {                       // wave-uniform loop: geom record lives in SGPRs
+    for (int i = 0; i < S.n_geoms; ++i) {
         const DevGeom g = load_geom_uniform(S.geoms, i);
         f3 tp, tn;
         if (g.type == 1) t = box_test(g, ro, rd, tp, tn);
         else if (g.type == 0) t = sphere_test(g, ro, rd, tp, tn);
-        if (t > 0.0f && t_min > t) { t_min = t; hit_geom = i; P = tp; NS = tn; }
+        if (t > 0.0f && a.t_min > t) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
     }
-    // threaded (stackless) BVH walk over the direction-ordered links (pathtrace.cu:236-279)
-    const int2* links = S.links + (size_t)mtbvh_dir(rd) * S.bvh_size;
-    f3 inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-    int idx = 0;
-    while (idx != -1) {
-        if (STATS) nodeVisits++;
-        const DevNode nd = S.nodes[idx];
-        const int2 lk = links[idx];
-        float tEnter;
-        if (!aabb_test(nd, ro, rd, inv, tEnter) || tEnter > t_min) { idx = lk.y; continue; }
-        if (nd.end - nd.start <= 1) {
-            for (int k = nd.start; k < nd.end; ++k) {
-                float tt, u, v;
-                if (STATS) triTests++;
-                if (tri_test(S.triv[k], ro, rd, tt, u, v) && t_min > tt) { t_min = tt; tri_id = k; bu = u; bv = v; }
-            }
+}
+// hit record of an analytic winner (pathtrace.cu:315-340 with the constant normal sampler)
+PTK_DI void analytic_record(const SceneView& S, const Analytic& a, Hit& h) {
+    h.t = a.t_min; h.p = a.P;
+    h.n = normalize(analytic_normal(S.geoms[a.geom], a.NS));     // per-lane geom index: one gather, once per ray
+    h.uv.x = 0.f; h.uv.y = 0.f;
+    h.mat = S.geoms[a.geom].materialid; h.geom = a.geom; h.tri = -1;
+}
+// (2) one traversal state per ray: threaded (stackless) walk over the direction-ordered nodes (pathtrace.cu:236-279)
+struct Walk { f3 o, d, inv; float t_min; int tri; float u, v; int idx; const DevNode* nodes; bool general; };
+PTK_DI void walk_begin(const SceneView& S, f3 ro, f3 rd, float t_min, Walk& w) {
+    w.o = ro; w.d = rd; w.inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    w.t_min = t_min; w.tri = -1; w.u = 0.f; w.v = 0.f; w.idx = 0;
+    w.nodes = S.nodes + (size_t)mtbvh_dir(rd) * S.bvh_size;
+    w.general = (rd.x == 0) || (rd.y == 0) || (rd.z == 0);       // needs the containment tests of Bounds3.hpp:174-177
+}
+// one node visit; returns the number of triangle tests it did (0/1).  When w.idx becomes -1 the walk is complete.
+PTK_DI int walk_step(const SceneView& S, Walk& w) {
+    const DevNode nd = w.nodes[w.idx];
+    float tEnter;
+    int tests = 0;
+    const bool in = w.general ? aabb_test(nd, w.o, w.d, w.inv, tEnter) : aabb_test_fast(nd, w.o, w.inv, tEnter);
+    if (!in || tEnter > w.t_min) { w.idx = nd.b; return 0; }
+    if (nd.a >= 0) { w.idx = nd.a; return 0; }
+    if (nd.a <= -2) {
+        const int k = -(nd.a + 2);
+        float tt, u, v;
+        tests = 1;
+        if (tri_test(S.trie[k], w.o, w.d, tt, u, v) && w.t_min > tt) { w.t_min = tt; w.tri = k; w.u = u; w.v = v; }
+    }
+    w.idx = nd.b;
+    return tests;
+}
+// (3) hit record of a triangle winner (pathtrace.cu:268-274, 315-340)
+PTK_DI void triangle_record(const SceneView& S, int tri, float bu, float bv, float t, Hit& h) {
+    const DevTriV& V = S.triv[tri];
+    const DevTriA& A = S.tria[tri];
+    const float w = 1 - bu - bv;
+    f3 P = w * mk3(V.v0[0], V.v0[1], V.v0[2]) + bu * mk3(V.v1[0], V.v1[1], V.v1[2]) + bv * mk3(V.v2[0], V.v2[1], V.v2[2]);
+    f3 N = w * mk3(A.n0[0], A.n0[1], A.n0[2]) + bu * mk3(A.n1[0], A.n1[1], A.n1[2]) + bv * mk3(A.n2[0], A.n2[1], A.n2[2]);
+    h.uv.x = gclamp(w * A.t0[0] + bu * A.t1[0] + bv * A.t2[0], 0.f, 1.f);
+    h.uv.y = gclamp(w * A.t0[1] + bu * A.t1[1] + bv * A.t2[1], 0.f, 1.f);
+    h.t = t; h.p = P; h.n = normalize(N);
+    h.geom = A.geomIdx; h.mat = S.geoms[A.geomIdx].materialid; h.tri = tri;
+}
+
+// computeIntersections body (pathtrace.cu:191-343) for one ray, everything in the calling lane.  Returns rayValid.
+template <bool STATS>
+PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
+    Analytic a;
+    analytic_closest(S, ro, rd, a);
+    int tri = -1; float bu = 0.f, bv = 0.f, t_min = a.t_min;
+    if (S.n_tris > 0) {                 // a triangle-free scene has one empty root per direction: it can never hit
+        Walk w;
+        walk_begin(S, ro, rd, a.t_min, w);
+        while (w.idx != -1) {
+            const int k = walk_step(S, w);
+            if (STATS) { nodeVisits++; triTests += k; }
         }
-        idx = lk.x;
-    }
-    if (tri_id >= 0) {
-        const DevTriV& V = S.triv[tri_id];
-        const DevTriA& A = S.tria[tri_id];
-        float w = 1 - bu - bv;
-        hit_geom = A.geomIdx;
-        P = w * mk3(V.v0[0], V.v0[1], V.v0[2]) + bu * mk3(V.v1[0], V.v1[1], V.v1[2]) + bv * mk3(V.v2[0], V.v2[1], V.v2[2]);
-        N = w * mk3(A.n0[0], A.n0[1], A.n0[2]) + bu * mk3(A.n1[0], A.n1[1], A.n1[2]) + bv * mk3(A.n2[0], A.n2[1], A.n2[2]);
-        h.uv.x = gclamp(w * A.t0[0] + bu * A.t1[0] + bv * A.t2[0], 0.f, 1.f);
-        h.uv.y = gclamp(w * A.t0[1] + bu * A.t1[1] + bv * A.t2[1], 0.f, 1.f);
-    } else {
-        h.uv.x = 0.f; h.uv.y = 0.f;
-        if (hit_geom >= 0) N = analytic_normal(S.geoms[hit_geom], NS);      // per-lane geom index: one gather, once per ray
-    }
-    if (hit_geom == -1) { h.t = -1.0f; return 0; }
-    h.t = t_min; h.p = P; h.n = normalize(N);
-    h.mat = S.geoms[hit_geom].materialid; h.geom = hit_geom; h.tri = tri_id;
+        tri = w.tri; bu = w.u; bv = w.v; t_min = w.t_min;
+    } else if (STATS) nodeVisits++;     // the reference still visits that empty root once
+    if (tri >= 0) { triangle_record(S, tri, bu, bv, t_min, h); return 1; }
+    if (a.geom == -1) { h.t = -1.0f; return 0; }
+    analytic_record(S, a, h);
     return 1;
 }
 
@@ -350,21 +396,22 @@ PTK_DI bool occluded(const SceneView& S, f3 ori, f3 dir, f3 des) {
         else if (g.type == 0) t = sphere_test(g, ori, dir, tp, tn);
         if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
     }
-    const int2* links = S.links + (size_t)mtbvh_dir(dir) * S.bvh_size;
+    if (S.n_tris == 0) return false;
+    const DevNode* nodes = S.nodes + (size_t)mtbvh_dir(dir) * S.bvh_size;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const bool general = (dir.x == 0) || (dir.y == 0) || (dir.z == 0);
     int idx = 0;
     while (idx != -1) {
-        const DevNode nd = S.nodes[idx];
-        const int2 lk = links[idx];
+        const DevNode nd = nodes[idx];
         float tEnter;
-        if (!aabb_test(nd, ori, dir, inv, tEnter) || tEnter > minT) { idx = lk.y; continue; }
-        if (nd.end - nd.start <= 1) {
-            for (int k = nd.start; k < nd.end; ++k) {
-                float tt, u, v;
-                if (tri_test(S.triv[k], ori, dir, tt, u, v) && minT - 1e-5f > tt && (double)fabsf(tt - minT) > 1e-4) return true;
-            }
+        const bool in = general ? aabb_test(nd, ori, dir, inv, tEnter) : aabb_test_fast(nd, ori, inv, tEnter);
+        if (!in || tEnter > minT) { idx = nd.b; continue; }
+        if (nd.a >= 0) { idx = nd.a; continue; }
+        if (nd.a <= -2) {
+            float tt, u, v;
+            if (tri_test(S.trie[-(nd.a + 2)], ori, dir, tt, u, v) && minT - 1e-5f > tt && (double)fabsf(tt - minT) > 1e-4) return true;
         }
-        idx = lk.x;
+        idx = nd.b;
     }
     return false;
 }

@@ -19,7 +19,7 @@ inline SceneView dev_view(const ::Scene& s) {
     d.geoms = (const DevGeom*)t.dev_geoms;       d.n_geoms = (int)s.geoms.size();
     d.mats = (const DevMaterial*)t.dev_materials; d.n_mats = (int)s.materials.size();
     d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
-    d.links = (const int2*)t.dev_links;
+    d.trie = (const DevTriE*)t.dev_trie;
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
     return d;
@@ -34,6 +34,9 @@ struct Workspace {               // per-render-context scratch, device memory
     int* counts = nullptr;       // live paths entering bounce d, d = 0..traceDepth  (device)
     unsigned long long* ray_total = nullptr;   // sum of counts over all iterations (device)
     unsigned long long* stats = nullptr;       // optional node/triangle counters
+    unsigned* queue = nullptr;   // length of the traversal work list (rays that entered the BVH root box)
+    int* list = nullptr;         // the work list [capacity]
+    bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     int capacity = 0;
 };
 

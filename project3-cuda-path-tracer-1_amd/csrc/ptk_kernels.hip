@@ -86,22 +86,52 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter,
 
 // ------------------------------------------------------------------------------------------------------------------
 // computeIntersections, pathtrace.cu:169-346
+//
+// Triangle-free scenes: k_intersect<*, false> does everything (analytic primitives only; the empty BVH root cannot hit).
+// Scenes with triangles run three kernels, because per-ray traversal cost is bimodal (bunny scene: ~80 % of the rays miss
+// the mesh's root box and cost 1 node visit, the rest ~60; with one ray per lane a wave runs for its slowest lane and lane
+// utilisation in the walk is ~15 %):
+//   k_intersect<*, true>  analytic primitives for every ray (uniform loop, no divergence) + the ROOT box test; rays that
+//                         enter the root box are appended to a work list (one wave-aggregated atomic per wave);
+//   k_traverse            the threaded-BVH walk, one listed ray per lane: every lane now holds a "heavy" ray.  List order is
+//                         arbitrary but rays are independent, so every per-ray result is the same for any order;
+//   k_finalize            turns (triangle, u, v, t) winners into full hit records (coalesced) and builds the per-block
+//                         aggregates the shading kernel's virtual compaction needs.
+// (A persistent-wave variant that refilled idle lanes from a global ray counter was measured and dropped: with ~400 rays
+//  per SIMD per bounce there are too few rays per wave for refill to reach a steady state; 2.5 ms vs 1.4 ms per iteration.)
 // ------------------------------------------------------------------------------------------------------------------
-template <bool STATS>
+#define PTK_VALID_TRI 2          // flag value between k_traverse and k_finalize: "closest hit is a triangle, record pending"
+
+template <bool STATS, bool SPLIT>
 __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
-                                                          unsigned long long* ray_total, unsigned long long* stats) {
+                                                          unsigned long long* ray_total, unsigned long long* stats,
+                                                          unsigned* list_count, int* __restrict__ list) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     if (i == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
     int flag = 0;
+    bool heavy = false;
     unsigned nv = 0, nt = 0;
     if (i < n) {
         const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i);
+        const f3 ro = mk3(o4.x, o4.y, o4.z), rd = mk3(d4.x, d4.y, d4.z);
         Hit h;
-        flag = closest_hit<STATS>(S, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), h, nv, nt);
+        if (SPLIT) {
+            Analytic a;
+            analytic_closest(S, ro, rd, a);
+            flag = a.geom >= 0;
+            if (flag) analytic_record(S, a, h);
+            // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
+            const DevNode root = S.nodes[(size_t)mtbvh_dir(rd) * S.bvh_size];
+            float tEnter;
+            heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
+            if (STATS && !heavy) nv = 1;
+        } else {
+            flag = closest_hit<STATS>(S, ro, rd, h, nv, nt);
+        }
         if (flag) {
             st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
             st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
@@ -110,6 +140,16 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
             st4(hits.t_n, i, make_float4(-1.f, 0.f, 0.f, 0.f));
         }
         valid[i] = flag;
+    }
+    if (SPLIT) {                                    // append the rays that entered the root box to the traversal list
+        const unsigned long long hm = __ballot(heavy);
+        if (hm) {
+            const int lane = threadIdx.x & 63;
+            unsigned base = 0;
+            if (lane == (__ffsll((long long)hm) - 1)) base = atomicAdd(list_count, (unsigned)__popcll(hm));
+            base = __shfl(base, __ffsll((long long)hm) - 1, 64);
+            if (heavy) list[base + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+        }
     }
     if (agg) {
         int total;
@@ -121,6 +161,66 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
+    }
+}
+
+// BVH traversal of the listed rays, one per lane (pathtrace.cu:236-279).  A triangle winner is parked as (u, v, t, tri) in
+// the ray's uv_ids slot with flag PTK_VALID_TRI; k_finalize expands it (and clears the list counter for the next bounce).
+template <bool STATS>
+__global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
+                                                         PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats) {
+    const int m = (int)*list_count;
+    const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (blockIdx.x * PTK_BLOCK >= m) return;
+    unsigned nv = 0, nt = 0;
+    if (j < m) {
+        const int ray = list[j];
+        const float4 o4 = ld4(paths.o_pix, ray), d4 = ld4(paths.d_bnc, ray);
+        const float t0 = hits.t_n[4 * (size_t)ray];                   // analytic closest t, -1 = none
+        Walk w;
+        walk_begin(S, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), t0 > 0.f ? t0 : FLT_MAX, w);
+        while (w.idx != -1) {
+            const int k = walk_step(S, w);
+            if (STATS) { nv++; nt += k; }
+        }
+        if (w.tri >= 0) {
+            st4(hits.uv_ids, ray, make_float4(w.u, w.v, w.t_min, __int_as_float(w.tri)));
+            valid[ray] = PTK_VALID_TRI;
+        }
+    }
+    if (STATS && stats) {
+        unsigned long long a = nv, c = nt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
+    }
+}
+
+__global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits,
+                                                         int* __restrict__ valid, int* __restrict__ agg, unsigned* list_count) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && list_count) *list_count = 0u;    // k_traverse (previous kernel) has consumed it
+    if (b * PTK_BLOCK >= n) return;
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    int flag = 0;
+    if (i < n) {
+        flag = valid[i];
+        if (flag == PTK_VALID_TRI) {
+            const float4 r = ld4(hits.uv_ids, i);
+            Hit h;
+            triangle_record(S, __float_as_int(r.w), r.x, r.y, r.z, h);
+            st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+            st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+            st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+            valid[i] = 1;
+            flag = 1;
+        }
+    }
+    if (agg) {
+        int total;
+        (void)block_excl_prefix(flag, total);
+        if (threadIdx.x == 0) agg[b] = total;
     }
 }
 
@@ -316,6 +416,10 @@ int launch_shade(int mode, const SceneView& S, int iter, int depth, int n, const
     return launch_rc();
 }
 
+unsigned* g_abi_queue = nullptr;       // traversal list counter + list for the kernel-level ptk_intersect entry point
+int* g_abi_list = nullptr;
+int g_abi_list_cap = 0;
+
 // scratch for the stand-alone ptk_compact entry point (per-block aggregates), grown on demand
 int* g_compact_agg = nullptr;
 int g_compact_agg_cap = 0;
@@ -349,6 +453,31 @@ int launch_generate(const ::Camera& cam, int iter, int traceDepth, PtkPaths path
     return launch_rc();
 }
 
+// intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
+int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
+                           unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, bool inline_bvh,
+                           hipStream_t st, void (*mark)(int, bool)) {
+    const int g = grid_for(n);
+    if (g == 0) return 0;
+    const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr;
+    mark(1, true);
+    if (!split) {
+        if (stats) k_intersect<true, false><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats, nullptr, nullptr);
+        else k_intersect<false, false><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr, nullptr, nullptr);
+        mark(1, false);
+        return launch_rc();
+    }
+    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, queue, list);
+    else k_intersect<false, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, queue, list);
+    int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
+    if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats);
+    else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr);
+    rc = launch_rc(); if (rc) { mark(1, false); return rc; }
+    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg, queue);
+    mark(1, false);
+    return launch_rc();
+}
+
 // one bounce of the staged pipeline: intersect -> shade (virtual compaction of misses) -> scatter survivors.
 // `capacity` bounds the launch; the live count is read from ws.counts[depth] on the device.
 static void no_mark(int, bool) {}
@@ -357,11 +486,9 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
     const int g = grid_for(capacity);
     if (g == 0) return 0;
     const int* d_n = ws.counts + depth;
-    mark(1, true);
-    if (ws.stats) k_intersect<true><<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats);
-    else k_intersect<false><<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, nullptr);
-    mark(1, false);
-    int rc = launch_rc(); if (rc) return rc;
+    int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
+                                    ws.inline_bvh, st, mark);
+    if (rc) return rc;
     mark(2, true);
     rc = launch_shade<true>(mode, S, iter, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, st);
     mark(2, false);
@@ -376,7 +503,6 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
                          PtkHits hits, float* img, const Workspace& ws, hipStream_t st) {
     return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark);
 }
-
 } // namespace ptk
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -396,10 +522,18 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
     if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid) return PTK_E_BADARG;
     if (n == 0) return 0;
-    const SceneView S = dev_view(*s->scene);
-    if (stats) k_intersect<true><<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, hits, valid, nullptr, nullptr, stats);
-    else k_intersect<false><<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, hits, valid, nullptr, nullptr, nullptr);
-    return launch_rc();
+    if (!g_abi_queue) {
+        hipError_t e = hipMalloc(&g_abi_queue, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
+        e = hipMemset(g_abi_queue, 0, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
+    }
+    if (n > g_abi_list_cap) {
+        if (g_abi_list) (void)hipFree(g_abi_list);
+        g_abi_list = nullptr; g_abi_list_cap = 0;
+        hipError_t e = hipMalloc(&g_abi_list, sizeof(int) * (size_t)n); if (e != hipSuccess) return (int)e;
+        g_abi_list_cap = n;
+    }
+    return launch_intersect_stage(dev_view(*s->scene), n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
+                                  false, (hipStream_t)stream, [](int, bool) {});
 }
 
 int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkHits hits_in,

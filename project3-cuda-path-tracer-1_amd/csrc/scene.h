@@ -100,8 +100,8 @@ public:
     int tri_num = 0, bvh_size = 0;
     void* dev_geoms = nullptr;        // ptk::DevGeom[]
     void* dev_materials = nullptr;    // ptk::DevMaterial[]
-    void* dev_nodes = nullptr;        // ptk::DevNode[bvh_size]
-    void* dev_links = nullptr;        // int2[6][bvh_size]
+    void* dev_nodes = nullptr;        // ptk::DevNode[6][bvh_size]
+    void* dev_trie = nullptr;         // ptk::DevTriE[]
     void* dev_triv = nullptr;         // ptk::DevTriV[]
     void* dev_tria = nullptr;         // ptk::DevTriA[]
     void* dev_lights = nullptr;       // ptk::DevLight[]
