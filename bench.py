@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--in-flight", type=int, default=1, help="iterations in flight (ptk_set_iterations_in_flight)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay iterations from a hipGraph")
+    ap.add_argument("--pipeline", type=int, default=0, help="ptk_set_pipeline value (A/B comparisons)")
     return ap.parse_args()
 
 
@@ -99,7 +102,7 @@ def main():
     res = tuple(a.res) if a.res else None
     scene = ptk.Scene(scene_path, res=res, depth=a.depth)
     part = (N, rank, a.tile_rows) if N > 1 else (1, 0, 1)
-    r = ptk.Renderer(scene, mode, partition=part)
+    r = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph))
     P = scene.width * scene.height
     red = torch.zeros((P, 3), dtype=torch.float32, device="cuda") if N > 1 else None
 

@@ -144,6 +144,14 @@ int ptk_pathtrace_free(void);                           /* pathtraceFree(), path
 int ptk_pathtrace(unsigned char* pbo, int frame, int iter);
 int ptk_set_sample_mode(int mode);                      /* `extern SampleMode sampleMode`, main.cpp:20 / pathtrace.cu:23 */
 int ptk_get_sample_mode(void);
+/* Iterations in flight (1..16, default 1; set before ptk_pathtrace_init).  With L > 1, iteration `it` runs on lane
+ * (it-1) % L (own stream, buffers and radiance plane), so consecutive ptk_pathtrace calls overlap on the GPU.  Every
+ * iteration is computed exactly as with L = 1; only the order of the per-pixel additions changes: plane l sums
+ * iterations l+1, l+1+L, ... and the image is ((plane0 + plane1) + plane2) + ...  Not a reference feature. */
+int ptk_set_iterations_in_flight(int lanes);
+/* 1: replay every iteration from a hipGraph captured once per lane (the kernels then read the iteration number from device
+ * memory); 0 (default): launch the kernels one by one.  Identical results; cuts the host cost per iteration. */
+int ptk_set_graph_replay(int on);
 /* Copy the running radiance SUM (not mean) into host memory, float[3*P], row-major x + y*W
  * (the per-iteration cudaMemcpy of pathtrace.cu:809-810, made lazy).  Synchronises. */
 int ptk_get_image(float* host_out);
@@ -162,9 +170,11 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 /* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
-/* Pipeline selection: 0 = staged kernels, BVH walked inside the intersect kernel, one ray per lane (default);
- * 1 = staged kernels, BVH walked by a separate kernel over a work list of the rays that enter the root box (A/B comparison;
- *     measured slower on MI355X: the contended list-append atomic costs more than the denser waves save). */
+/* Pipeline selection (A/B comparisons; all produce identical results):
+ *   0 = staged kernels, BVH walked inside the intersect kernel, one ray per lane (default);
+ *   1 = BVH walked by a separate kernel over a work list of the rays that enter the root box (measured slower: the
+ *       contended list-append atomic costs more than the denser waves save);
+ *   2 = like 0 with two rays per lane (measured slower: the walk is bounded by its longest dependent chain). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 

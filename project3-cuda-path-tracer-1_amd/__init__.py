@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
-    "ptk_partition_count", "ptk_partition_pixel",
+    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay",
 ]
 
 
@@ -124,6 +124,8 @@ def _load() -> C.CDLL:
     lib.ptk_get_ray_total.argtypes = [C.POINTER(C.c_ulonglong)]
     lib.ptk_set_tile_partition.argtypes = [ci, ci, ci]
     lib.ptk_set_pipeline.argtypes = [ci]
+    lib.ptk_set_iterations_in_flight.argtypes = [ci]
+    lib.ptk_set_graph_replay.argtypes = [ci]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
     lib.ptk_profile_end.argtypes = [vp, vp]
     lib.ptk_enable_traversal_stats.argtypes = [ci]
@@ -256,9 +258,12 @@ def tonemap(img, w: int, h: int, it: int, pbo):
 class Renderer:
     """File-static render context of the library (one at a time, like the reference)."""
 
-    def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1), pipeline: int = 0):
+    def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1), pipeline: int = 0, in_flight: int = 1,
+                 graph: bool = False):
         self.scene = scene
         lib.ptk_pathtrace_free()
+        _chk(lib.ptk_set_graph_replay(1 if graph else 0), "ptk_set_graph_replay")
+        _chk(lib.ptk_set_iterations_in_flight(in_flight), "ptk_set_iterations_in_flight")
         _chk(lib.ptk_set_pipeline(pipeline), "ptk_set_pipeline")
         _chk(lib.ptk_set_tile_partition(*partition), "ptk_set_tile_partition")
         _chk(lib.ptk_set_sample_mode(mode), "ptk_set_sample_mode")
@@ -320,3 +325,5 @@ class Renderer:
     def close(self):
         lib.ptk_pathtrace_free()
         lib.ptk_set_tile_partition(1, 0, 1)
+        lib.ptk_set_iterations_in_flight(1)
+        lib.ptk_set_graph_replay(0)

@@ -5,6 +5,14 @@
 // counts resident on the device (the reference does 4 blocking 4-byte D2H copies, a cudaDeviceSynchronize,
 // a full-frame cudaMemset and a cudaMalloc/cudaFree pair per bounce/iteration).  Nothing here synchronises
 // with the host; image / counts are fetched lazily by the accessors.
+//
+// ITERATIONS IN FLIGHT.  Iterations only interact by addition into the radiance buffer, so the context can hold L
+// independent "lanes" (stream + path/hit/flag buffers + counts + one radiance plane each); iteration `it` runs on lane
+// (it - 1) % L, and consecutive pathtrace() calls therefore overlap on the GPU.  Every iteration still executes exactly the
+// reference's algorithm with the reference's RNG keys; only the order of the per-pixel float additions changes:
+// plane l accumulates iterations l+1, l+1+L, ... in order, and the image is ((plane0 + plane1) + plane2) + ...
+// L = 1 (default) reproduces the reference's accumulation order.  This matters on MI355X because late bounces, BVH walks
+// (chains of dependent loads with ~1 wave per SIMD left) and tile-sharded frames leave most of the 256 CUs idle.
 #include "ptk_internal.h"
 #include "pathtrace.h"
 #include <cstdio>
@@ -17,18 +25,37 @@ __attribute__((weak)) SampleMode sampleMode = MIS;       // main.cpp:20 (the app
 
 namespace {
 
-struct RenderContext {
-    Scene* scene = nullptr;
-    GuiDataContainer* gui = nullptr;
+constexpr int kMaxLanes = 16;
+
+struct Lane {
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float* image = nullptr;             // float[3*P] running radiance sum (full frame even when tiled)
+    hipEvent_t done = nullptr;
     PtkPaths bufA = {nullptr, nullptr, nullptr}, bufB = {nullptr, nullptr, nullptr};
     PtkHits hits = {nullptr, nullptr, nullptr};
     Workspace ws;
+    float* plane = nullptr;             // float[3*P] radiance sum of this lane's iterations (points into RenderContext::planes)
+    int last_iter = 0;
+    // hipGraph replay of one iteration (all launches of render_iteration): the iteration number lives on the device
+    int* iter_dev = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_mode = -1;
+    int expected_iter = 0;              // value *iter_dev will hold when the next replay starts
+};
+
+struct RenderContext {
+    Scene* scene = nullptr;
+    GuiDataContainer* gui = nullptr;
+    std::vector<Lane> lanes;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float* planes = nullptr;            // float[L][3*P]
+    float* image = nullptr;             // float[3*P]: plane sum when L > 1 (== planes when L == 1)
+    unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
     int n_parts = 1, part = 0, tile_rows = 1;
-    int pipeline = 0;
+    int pipeline = 0, n_lanes = 1;
+    bool use_graph = false;
+    int last_lane = 0;
     bool live = false;
 } g;
 
@@ -40,6 +67,7 @@ template <typename T> int dalloc(T** p, size_t count) {
     return e == hipSuccess ? 0 : (int)e;
 }
 template <typename T> void dfree(T*& p) { if (p) (void)hipFree(p); p = nullptr; }
+inline int rc_of(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 int alloc_paths(PtkPaths& b, int cap) {
     int rc;
@@ -49,17 +77,56 @@ int alloc_paths(PtkPaths& b, int cap) {
 }
 void free_paths(PtkPaths& b) { dfree(b.o_pix); dfree(b.d_bnc); dfree(b.col_pdf); }
 
+void sync_all() { for (Lane& l : g.lanes) if (l.stream) (void)hipStreamSynchronize(l.stream); }
+
 int context_free() {
-    if (g.stream) (void)hipStreamSynchronize(g.stream);
-    dfree(g.image);
-    free_paths(g.bufA); free_paths(g.bufB);
-    dfree(g.hits.t_n); dfree(g.hits.p_mat); dfree(g.hits.uv_ids);
-    dfree(g.ws.agg_a); dfree(g.ws.agg_b); dfree(g.ws.valid_a); dfree(g.ws.valid_b);
-    dfree(g.ws.counts); dfree(g.ws.ray_total); dfree(g.ws.stats); dfree(g.ws.queue); dfree(g.ws.list);
+    sync_all();
+    for (Lane& l : g.lanes) {
+        free_paths(l.bufA); free_paths(l.bufB);
+        dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
+        dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
+        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
+        if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
+        if (l.graph) (void)hipGraphDestroy(l.graph);
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    g.lanes.clear();
+    if (g.image != g.planes) dfree(g.image);
+    g.image = nullptr;
+    dfree(g.planes); dfree(g.ray_total);
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
-    if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
     g.live = false; g.scene = nullptr; g.P = g.capacity = 0;
+    return 0;
+}
+
+int lane_init(Lane& l, int idx) {
+    int rc;
+    hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    l.plane = g.planes + (size_t)idx * 3 * (size_t)g.P;
+    if ((rc = alloc_paths(l.bufA, g.capacity))) return rc;
+    if ((rc = alloc_paths(l.bufB, g.capacity))) return rc;
+    if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.hits.p_mat, 4 * (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.hits.uv_ids, 4 * (size_t)g.capacity))) return rc;
+    const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;       // +2: k_intersect2 writes aggregates in pairs
+    if ((rc = dalloc(&l.ws.agg_a, blocks))) return rc;
+    if ((rc = dalloc(&l.ws.agg_b, blocks))) return rc;
+    if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.valid_b, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.counts, (size_t)g.traceDepth + 2))) return rc;
+    if ((rc = dalloc(&l.ws.queue, 1))) return rc;
+    if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.iter_dev, 1))) return rc;
+    if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
+    l.ws.ray_total = g.ray_total;
+    l.ws.inline_bvh = (g.pipeline != 1);
+    l.ws.capacity = g.capacity;
+    l.last_iter = 0;
     return 0;
 }
 
@@ -71,34 +138,21 @@ int context_init(Scene* scene) {
     g.scene = scene;
     g.P = cam.resolution.x * cam.resolution.y;
     g.traceDepth = scene->state.traceDepth;
-    if (g.traceDepth < 1) return PTK_E_BADARG;
+    if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
     g.capacity = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
     int rc;
-    hipError_t e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e;
     if ((e = hipEventCreate(&g.ev0)) != hipSuccess) return (int)e;
     if ((e = hipEventCreate(&g.ev1)) != hipSuccess) return (int)e;
-    if ((rc = dalloc(&g.image, 3 * (size_t)g.P))) return rc;
-    if ((e = hipMemsetAsync(g.image, 0, sizeof(float) * 3 * (size_t)g.P, g.stream)) != hipSuccess) return (int)e;
-    if ((rc = alloc_paths(g.bufA, g.capacity))) return rc;
-    if ((rc = alloc_paths(g.bufB, g.capacity))) return rc;
-    if ((rc = dalloc(&g.hits.t_n, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&g.hits.p_mat, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&g.hits.uv_ids, 4 * (size_t)g.capacity))) return rc;
-    const size_t blocks = ((size_t)g.capacity + 255) / 256;
-    if ((rc = dalloc(&g.ws.agg_a, blocks))) return rc;
-    if ((rc = dalloc(&g.ws.agg_b, blocks))) return rc;
-    if ((rc = dalloc(&g.ws.valid_a, (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&g.ws.valid_b, (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&g.ws.counts, (size_t)g.traceDepth + 2))) return rc;
-    if ((rc = dalloc(&g.ws.ray_total, 1))) return rc;
-    if ((rc = dalloc(&g.ws.queue, 1))) return rc;
-    if ((rc = dalloc(&g.ws.list, (size_t)g.capacity))) return rc;
-    if ((e = hipMemsetAsync(g.ws.queue, 0, sizeof(unsigned), g.stream)) != hipSuccess) return (int)e;
-    g.ws.inline_bvh = (g.pipeline == 0);
-    if ((e = hipMemsetAsync(g.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), g.stream)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(g.ws.ray_total, 0, sizeof(unsigned long long), g.stream)) != hipSuccess) return (int)e;
-    g.ws.capacity = g.capacity;
+    const size_t plane = 3 * (size_t)g.P;
+    if ((rc = dalloc(&g.planes, plane * g.n_lanes))) return rc;
+    if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * g.n_lanes)) != hipSuccess) return (int)e;
+    if (g.n_lanes > 1) { if ((rc = dalloc(&g.image, plane))) return rc; } else g.image = g.planes;
+    if ((rc = dalloc(&g.ray_total, 1))) return rc;
+    if ((e = hipMemset(g.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return (int)e;
+    g.lanes.assign(g.n_lanes, Lane());
+    for (int i = 0; i < g.n_lanes; ++i) if ((rc = lane_init(g.lanes[i], i))) return rc;
+    g.last_lane = 0;
     g.live = true;
     return 0;
 }
@@ -108,40 +162,96 @@ int current_mode() { return g_mode_override >= 0 ? g_mode_override : (int)sample
 // optional per-kernel timing (bench.py's roofline leg): HIP events on the render stream around every launch
 struct KernelProfile {
     bool on = false;
+    hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;          // pairs
-    std::vector<int> cls;                // PTK_KCLASS_* per pair
+    std::vector<int> cls;                // kernel class per pair
 } g_prof;
 
 void prof_mark(int cls, bool begin) {
     if (!g_prof.on) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
-    (void)hipEventRecord(e, g.stream);
+    (void)hipEventRecord(e, g_prof.stream);
     g_prof.ev.push_back(e);
     if (begin) g_prof.cls.push_back(cls);
 }
 
-int render_iteration(unsigned char* pbo, int iter) {
-    if (!g.live) return PTK_E_NOSCENE;
-    if (iter < 1) return PTK_E_BADARG;
+int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     const Camera& cam = g.scene->state.camera;
     const SceneView S = dev_view(*g.scene);
+    Workspace ws = L.ws;
+    ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
+    ws.iter_stride = g.n_lanes;
     prof_mark(0, true);
-    int rc = launch_generate(cam, iter, g.traceDepth, g.bufA, g.n_parts, g.part, g.tile_rows, g.capacity, g.ws.counts, g.stream);
+    int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, g.n_parts, g.part, g.tile_rows, g.capacity, ws.counts, L.stream);
     prof_mark(0, false);
     if (rc) return rc;
-    PtkPaths cur = g.bufA, nxt = g.bufB;
-    const int mode = current_mode();
+    PtkPaths cur = L.bufA, nxt = L.bufB;
     for (int depth = 0; depth < g.traceDepth; ++depth) {
-        if (g_prof.on) {
-            rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, g.hits, g.image, g.ws, g.stream, prof_mark);
-        } else {
-            rc = launch_bounce_staged(S, mode, iter, depth, g.capacity, cur, nxt, g.hits, g.image, g.ws, g.stream);
-        }
+        const bool last = depth == g.traceDepth - 1;
+        if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
+        else rc = launch_bounce_staged(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, last);
         if (rc) return rc;
         PtkPaths t = cur; cur = nxt; nxt = t;
     }
-    if (pbo) rc = ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter, pbo, g.stream);
+    return 0;
+}
+
+// Replay path: the launches of one iteration are captured once per lane into a hipGraph whose kernels read the iteration
+// number from L.iter_dev (stepped by n_lanes at the end of every replay), so a replay needs no argument patching.
+int replay_iteration(Lane& L, int iter, int mode) {
+    hipError_t e;
+    if (!L.graph_exec || L.graph_mode != mode) {
+        if (L.graph_exec) { (void)hipGraphExecDestroy(L.graph_exec); L.graph_exec = nullptr; }
+        if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; }
+        if ((e = hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return (int)e;
+        int rc = enqueue_iteration(L, iter, mode, true);
+        e = hipStreamEndCapture(L.stream, &L.graph);
+        if (rc) return rc;
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipGraphInstantiate(&L.graph_exec, L.graph, nullptr, nullptr, 0)) != hipSuccess) return (int)e;
+        L.graph_mode = mode;
+        L.expected_iter = -1;
+    }
+    if (L.expected_iter != iter) {           // first replay, or the caller jumped in the iteration sequence
+        if ((e = hipMemcpyAsync(L.iter_dev, &iter, sizeof(int), hipMemcpyHostToDevice, L.stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamSynchronize(L.stream)) != hipSuccess) return (int)e;     // &iter is a stack address
+    }
+    if ((e = hipGraphLaunch(L.graph_exec, L.stream)) != hipSuccess) return (int)e;
+    L.expected_iter = iter + g.n_lanes;
+    return 0;
+}
+
+int render_iteration(unsigned char* pbo, int iter) {
+    (void)pbo;
+    if (!g.live) return PTK_E_NOSCENE;
+    if (iter < 1) return PTK_E_BADARG;
+    const int li = (iter - 1) % g.n_lanes;
+    Lane& L = g.lanes[li];
+    g.last_lane = li;
+    L.last_iter = iter;
+    g_prof.stream = L.stream;
+    const int mode = current_mode();
+    if (g.use_graph && !g_prof.on && !L.ws.stats) return replay_iteration(L, iter, mode);
+    L.expected_iter = -1;
+    return enqueue_iteration(L, iter, mode, false);
+}
+
+// all lanes' work so far -> visible to lane 0's stream (event edges only, no host wait)
+int join_on_lane0() {
+    for (size_t i = 1; i < g.lanes.size(); ++i) {
+        hipError_t e = hipEventRecord(g.lanes[i].done, g.lanes[i].stream);
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipStreamWaitEvent(g.lanes[0].stream, g.lanes[i].done, 0)) != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// image = ((plane0 + plane1) + plane2) + ...   on lane 0's stream, after joining the other lanes
+int resolve_image() {
+    int rc = join_on_lane0();
+    if (rc) return rc;
+    if (g.n_lanes > 1) rc = launch_sum_planes(g.planes, g.n_lanes, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
     return rc;
 }
 
@@ -158,43 +268,70 @@ extern "C" {
 
 int ptk_pathtrace_init(PtkScene* s) { if (!s || !s->scene) return PTK_E_NOSCENE; return context_init(s->scene); }
 int ptk_pathtrace_free(void) { return context_free(); }
-int ptk_pathtrace(unsigned char* pbo, int frame, int iter) { (void)frame; return render_iteration(pbo, iter); }
+
+int ptk_pathtrace(unsigned char* pbo, int frame, int iter) {
+    (void)frame;
+    int rc = render_iteration(pbo, iter);
+    if (rc || !pbo) return rc;
+    if ((rc = resolve_image())) return rc;
+    const Camera& cam = g.scene->state.camera;
+    return ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter, pbo, g.lanes[0].stream);
+}
+
 int ptk_set_sample_mode(int mode) { if (mode < 0 || mode > 2) return PTK_E_BADARG; g_mode_override = mode; return 0; }
 int ptk_get_sample_mode(void) { return current_mode(); }
+
+int ptk_set_iterations_in_flight(int lanes) {
+    if (lanes < 1 || lanes > kMaxLanes || g.live) return PTK_E_BADARG;     // set before ptk_pathtrace_init
+    g.n_lanes = lanes;
+    return 0;
+}
+
+/* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
+int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
 
 int ptk_get_image(float* host_out) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!host_out) return PTK_E_BADARG;
-    hipError_t e = hipMemcpyAsync(host_out, g.image, sizeof(float) * 3 * (size_t)g.P, hipMemcpyDeviceToHost, g.stream);
+    int rc = resolve_image();
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(host_out, g.image, sizeof(float) * 3 * (size_t)g.P, hipMemcpyDeviceToHost, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(g.stream);
-    return e == hipSuccess ? 0 : (int)e;
+    return rc_of(hipStreamSynchronize(g.lanes[0].stream));
 }
-int ptk_get_image_device(float** out) { if (!g.live) return PTK_E_NOSCENE; if (!out) return PTK_E_BADARG; *out = g.image; return 0; }
+int ptk_get_image_device(float** out) {
+    if (!g.live) return PTK_E_NOSCENE;
+    if (!out) return PTK_E_BADARG;
+    int rc = resolve_image();
+    if (rc) return rc;
+    if ((rc = rc_of(hipStreamSynchronize(g.lanes[0].stream)))) return rc;
+    *out = g.image;
+    return 0;
+}
 int ptk_copy_image_to_device(float* dst) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!dst) return PTK_E_BADARG;
-    hipError_t e = hipMemcpyAsync(dst, g.image, sizeof(float) * 3 * (size_t)g.P, hipMemcpyDeviceToDevice, g.stream);
+    int rc = resolve_image();
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dst, g.image, sizeof(float) * 3 * (size_t)g.P, hipMemcpyDeviceToDevice, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(g.stream);
-    return e == hipSuccess ? 0 : (int)e;
+    return rc_of(hipStreamSynchronize(g.lanes[0].stream));
 }
-int ptk_get_live_counts(int* counts, int* traced_depth) {
+int ptk_get_live_counts(int* counts, int* traced_depth) {          // of the LAST ptk_pathtrace call
     if (!g.live) return PTK_E_NOSCENE;
     if (!counts) return PTK_E_BADARG;
-    hipError_t e = hipMemcpyAsync(counts, g.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, g.stream);
+    Lane& L = g.lanes[g.last_lane];
+    hipError_t e = hipMemcpyAsync(counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
     if (e != hipSuccess) return (int)e;
-    if ((e = hipStreamSynchronize(g.stream)) != hipSuccess) return (int)e;
+    if ((e = hipStreamSynchronize(L.stream)) != hipSuccess) return (int)e;
     if (traced_depth) { int d = 0; while (d < g.traceDepth && counts[d] > 0) ++d; *traced_depth = d; }
     return 0;
 }
 int ptk_get_ray_total(unsigned long long* rays) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!rays) return PTK_E_BADARG;
-    hipError_t e = hipMemcpyAsync(rays, g.ws.ray_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(g.stream);
-    return e == hipSuccess ? 0 : (int)e;
+    sync_all();
+    return rc_of(hipMemcpy(rays, g.ray_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 }
 int ptk_set_tile_partition(int n_parts, int part, int tile_rows) {
     if (n_parts < 1 || part < 0 || part >= n_parts || tile_rows < 1) return PTK_E_BADARG;
@@ -215,8 +352,10 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     return x + y * W;
 }
 int ptk_set_pipeline(int which) {
-    if (which != 0 && which != 1) return PTK_E_BADARG;
-    g.pipeline = which; g.ws.inline_bvh = (which == 0);
+    if (which < 0 || which > 2) return PTK_E_BADARG;
+    g.pipeline = which;
+    for (Lane& l : g.lanes) l.ws.inline_bvh = (which != 1);
+    set_rays_per_lane(which == 2 ? 2 : 1);
     return 0;
 }
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the
@@ -232,8 +371,7 @@ int ptk_profile_end(float* ms4, int* launches4) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!ms4 || !launches4) return PTK_E_BADARG;
     g_prof.on = false;
-    hipError_t e = hipStreamSynchronize(g.stream);
-    if (e != hipSuccess) return (int)e;
+    sync_all();
     for (int k = 0; k < 4; ++k) { ms4[k] = 0.f; launches4[k] = 0; }
     for (size_t i = 0; i < g_prof.cls.size() && 2 * i + 1 < g_prof.ev.size(); ++i) {
         float ms = 0.f;
@@ -246,32 +384,46 @@ int ptk_profile_end(float* ms4, int* launches4) {
 /* Enable (1) / disable (0) the BVH traversal counters; read them with ptk_get_traversal_stats (node visits, triangle tests). */
 int ptk_enable_traversal_stats(int on) {
     if (!g.live) return PTK_E_NOSCENE;
-    if (on && !g.ws.stats) {
-        int rc = dalloc(&g.ws.stats, 2); if (rc) return rc;
-        hipError_t e = hipMemsetAsync(g.ws.stats, 0, 2 * sizeof(unsigned long long), g.stream);
-        return e == hipSuccess ? 0 : (int)e;
+    sync_all();
+    for (Lane& l : g.lanes) {
+        if (on && !l.ws.stats) {
+            int rc = dalloc(&l.ws.stats, 2); if (rc) return rc;
+            hipError_t e = hipMemset(l.ws.stats, 0, 2 * sizeof(unsigned long long));
+            if (e != hipSuccess) return (int)e;
+        }
+        if (!on && l.ws.stats) dfree(l.ws.stats);
     }
-    if (!on && g.ws.stats) { (void)hipStreamSynchronize(g.stream); dfree(g.ws.stats); }
     return 0;
 }
 int ptk_get_traversal_stats(unsigned long long* out2) {
-    if (!g.live || !g.ws.stats) return PTK_E_NOSCENE;
+    if (!g.live) return PTK_E_NOSCENE;
     if (!out2) return PTK_E_BADARG;
-    hipError_t e = hipMemcpyAsync(out2, g.ws.stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(g.stream);
-    return e == hipSuccess ? 0 : (int)e;
+    sync_all();
+    out2[0] = out2[1] = 0;
+    for (Lane& l : g.lanes) {
+        if (!l.ws.stats) return PTK_E_NOSCENE;
+        unsigned long long v[2];
+        hipError_t e = hipMemcpy(v, l.ws.stats, sizeof v, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return (int)e;
+        out2[0] += v[0]; out2[1] += v[1];
+    }
+    return 0;
 }
-int ptk_stream_sync(void) { if (!g.live) return PTK_E_NOSCENE; hipError_t e = hipStreamSynchronize(g.stream); return e == hipSuccess ? 0 : (int)e; }
-int ptk_timer_start(void) { if (!g.live) return PTK_E_NOSCENE; hipError_t e = hipEventRecord(g.ev0, g.stream); return e == hipSuccess ? 0 : (int)e; }
+int ptk_stream_sync(void) { if (!g.live) return PTK_E_NOSCENE; sync_all(); return 0; }
+int ptk_timer_start(void) {
+    if (!g.live) return PTK_E_NOSCENE;
+    sync_all();
+    return rc_of(hipEventRecord(g.ev0, g.lanes[0].stream));
+}
 int ptk_timer_stop(float* ms) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!ms) return PTK_E_BADARG;
-    hipError_t e = hipEventRecord(g.ev1, g.stream);
+    int rc = join_on_lane0();
+    if (rc) return rc;
+    hipError_t e = hipEventRecord(g.ev1, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventSynchronize(g.ev1)) != hipSuccess) return (int)e;
-    e = hipEventElapsedTime(ms, g.ev0, g.ev1);
-    return e == hipSuccess ? 0 : (int)e;
+    return rc_of(hipEventElapsedTime(ms, g.ev0, g.ev1));
 }
 
 } // extern "C"
@@ -284,8 +436,7 @@ void pathtraceInit(Scene* scene) { PTK_CHECK("pathtraceInit", context_init(scene
 void pathtraceFree() { PTK_CHECK("pathtraceFree", context_free()); }
 
 void pathtrace(uchar4* pbo, int frame, int iteration) {
-    (void)frame;
-    PTK_CHECK("pathtrace", render_iteration(reinterpret_cast<unsigned char*>(pbo), iteration));
+    PTK_CHECK("pathtrace", ptk_pathtrace(reinterpret_cast<unsigned char*>(pbo), frame, iteration));
     // pathtrace.cu:809-810: the host copy of the running sum is refreshed after every call
     std::vector<ptk::vec3>& img = g.scene->state.image;
     if ((int)img.size() != g.P) img.assign((size_t)g.P, ptk::vec3());

@@ -335,8 +335,12 @@ PTK_DI void walk_begin(const SceneView& S, f3 ro, f3 rd, float t_min, Walk& w) {
     w.general = (rd.x == 0) || (rd.y == 0) || (rd.z == 0);       // needs the containment tests of Bounds3.hpp:174-177
 }
 // one node visit; returns the number of triangle tests it did (0/1).  When w.idx becomes -1 the walk is complete.
+PTK_DI int walk_apply(const SceneView& S, Walk& w, const DevNode& nd);
 PTK_DI int walk_step(const SceneView& S, Walk& w) {
     const DevNode nd = w.nodes[w.idx];
+    return walk_apply(S, w, nd);
+}
+PTK_DI int walk_apply(const SceneView& S, Walk& w, const DevNode& nd) {
     float tEnter;
     int tests = 0;
     const bool in = w.general ? aabb_test(nd, w.o, w.d, w.inv, tEnter) : aabb_test_fast(nd, w.o, w.inv, tEnter);

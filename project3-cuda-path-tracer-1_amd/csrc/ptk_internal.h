@@ -36,16 +36,20 @@ struct Workspace {               // per-render-context scratch, device memory
     unsigned long long* stats = nullptr;       // optional node/triangle counters
     unsigned* queue = nullptr;   // length of the traversal work list (rays that entered the BVH root box)
     int* list = nullptr;         // the work list [capacity]
+    int* iter_dev = nullptr;     // device-resident iteration number (hipGraph replay); null = use the launch argument
+    int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     int capacity = 0;
 };
 
-int launch_generate(const ::Camera& cam, int iter, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
+int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
                     int n_local, int* d_count0, hipStream_t st);
 int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
-                         PtkHits hits, float* img, const Workspace& ws, hipStream_t st);
+                         PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce);
 int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
-                                  PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool));
+                                  PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce);
+void set_rays_per_lane(int k);
+int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);
 
 } // namespace ptk

@@ -67,8 +67,9 @@ struct DevCamera { int W, H; f3 pos, view, up, right; float plx, ply; };
 // ------------------------------------------------------------------------------------------------------------------
 // generateRayFromCamera, pathtrace.cu:135-163.  Path j -> pixel (x,y) through the tile partition.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter, int traceDepth, PtkPaths paths,
-                                                         int n_parts, int part, int tile_rows, int n_local, int* count0) {
+__global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_arg, const int* __restrict__ iter_ptr, int traceDepth,
+                                                         PtkPaths paths, int n_parts, int part, int tile_rows, int n_local, int* count0) {
+    const int iter = iter_ptr ? *iter_ptr : iter_arg;      // device-resident iteration number when replayed from a hipGraph
     const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (j == 0 && count0) *count0 = n_local;
     if (j >= n_local) return;
@@ -155,6 +156,95 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
         int total;
         (void)block_excl_prefix(flag, total);
         if (threadIdx.x == 0) agg[b] = total;
+    }
+    if (STATS && stats) {
+        unsigned long long a = nv, c = nt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
+    }
+}
+
+// Two rays per lane (ILP-2 form of the one-kernel layout; pipeline 2, measured SLOWER than one ray per lane on MI355X:
+// bunny scene 1.54 vs 1.17 ms of intersect time per iteration, cornell 0.29 vs 0.26 — kept for A/B runs only).  Thread t of block b owns paths b*512 + t and b*512 + 256 + t, so
+// every wave access stays coalesced and the flag aggregates still cover 256-path ranges (agg[2b], agg[2b+1]).
+// Why: (1) the threaded-BVH walk is a chain of dependent 32-B loads and, once the cheap rays have retired, only 2-3 waves
+// per SIMD are left to hide their latency; walking two independent rays per lane issues both node loads before either test,
+// halving the exposed latency per visit; (2) each SGPR-resident primitive record is used for two rays per scalar load.
+template <bool STATS>
+__global__ void __launch_bounds__(PTK_BLOCK) k_intersect2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
+                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
+                                                           unsigned long long* ray_total, unsigned long long* stats) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * (2 * PTK_BLOCK) >= n) return;
+    const int i0 = b * (2 * PTK_BLOCK) + threadIdx.x, i1 = i0 + PTK_BLOCK;
+    if (i0 == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
+    const bool on0 = i0 < n, on1 = i1 < n;
+    const float4 o40 = on0 ? ld4(paths.o_pix, i0) : make_float4(0, 0, 0, 0), d40 = on0 ? ld4(paths.d_bnc, i0) : make_float4(1, 0, 0, 0);
+    const float4 o41 = on1 ? ld4(paths.o_pix, i1) : make_float4(0, 0, 0, 0), d41 = on1 ? ld4(paths.d_bnc, i1) : make_float4(1, 0, 0, 0);
+    const f3 ro0 = mk3(o40.x, o40.y, o40.z), rd0 = mk3(d40.x, d40.y, d40.z);
+    const f3 ro1 = mk3(o41.x, o41.y, o41.z), rd1 = mk3(d41.x, d41.y, d41.z);
+    Analytic a0, a1;
+    a0.t_min = a1.t_min = FLT_MAX; a0.geom = a1.geom = -1;
+    a0.P = a1.P = a0.NS = a1.NS = mk3(0, 0, 0);
+    {
+        float t0 = -1.f, t1 = -1.f;
+        for (int i = 0; i < S.n_geoms; ++i) {                    // one scalar load of the primitive, two rays tested
+            const DevGeom g = load_geom_uniform(S.geoms, i);
+            f3 p0, s0, p1, s1;
+            if (g.type == 1) { t0 = box_test(g, ro0, rd0, p0, s0); t1 = box_test(g, ro1, rd1, p1, s1); }
+            else if (g.type == 0) { t0 = sphere_test(g, ro0, rd0, p0, s0); t1 = sphere_test(g, ro1, rd1, p1, s1); }
+            if (t0 > 0.0f && a0.t_min > t0) { a0.t_min = t0; a0.geom = i; a0.P = p0; a0.NS = s0; }
+            if (t1 > 0.0f && a1.t_min > t1) { a1.t_min = t1; a1.geom = i; a1.P = p1; a1.NS = s1; }
+        }
+    }
+    unsigned nv = 0, nt = 0;
+    int tri0 = -1, tri1 = -1; float u0 = 0, v0 = 0, u1 = 0, v1 = 0, tm0 = a0.t_min, tm1 = a1.t_min;
+    if (S.n_tris > 0) {
+        Walk w0, w1;
+        walk_begin(S, ro0, rd0, a0.t_min, w0);
+        walk_begin(S, ro1, rd1, a1.t_min, w1);
+        if (!on0) w0.idx = -1;
+        if (!on1) w1.idx = -1;
+        while (w0.idx != -1 || w1.idx != -1) {
+            const bool act0 = w0.idx != -1, act1 = w1.idx != -1;
+            const DevNode n0 = w0.nodes[act0 ? w0.idx : 0];      // both loads are issued before either test
+            const DevNode n1 = w1.nodes[act1 ? w1.idx : 0];
+            if (act0) { const int k = walk_apply(S, w0, n0); if (STATS) { nv++; nt += k; } }
+            if (act1) { const int k = walk_apply(S, w1, n1); if (STATS) { nv++; nt += k; } }
+        }
+        tri0 = w0.tri; u0 = w0.u; v0 = w0.v; tm0 = w0.t_min;
+        tri1 = w1.tri; u1 = w1.u; v1 = w1.v; tm1 = w1.t_min;
+    } else if (STATS) nv += (on0 ? 1 : 0) + (on1 ? 1 : 0);
+    int f0 = 0, f1 = 0;
+    if (on0) {
+        Hit h;
+        if (tri0 >= 0) { triangle_record(S, tri0, u0, v0, tm0, h); f0 = 1; }
+        else if (a0.geom >= 0) { analytic_record(S, a0, h); f0 = 1; }
+        if (f0) {
+            st4(hits.t_n, i0, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+            st4(hits.p_mat, i0, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+            st4(hits.uv_ids, i0, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+        } else st4(hits.t_n, i0, make_float4(-1.f, 0.f, 0.f, 0.f));
+        valid[i0] = f0;
+    }
+    if (on1) {
+        Hit h;
+        if (tri1 >= 0) { triangle_record(S, tri1, u1, v1, tm1, h); f1 = 1; }
+        else if (a1.geom >= 0) { analytic_record(S, a1, h); f1 = 1; }
+        if (f1) {
+            st4(hits.t_n, i1, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+            st4(hits.p_mat, i1, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+            st4(hits.uv_ids, i1, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+        } else st4(hits.t_n, i1, make_float4(-1.f, 0.f, 0.f, 0.f));
+        valid[i1] = f1;
+    }
+    if (agg) {
+        int tot0, tot1;
+        (void)block_excl_prefix(f0, tot0);
+        (void)block_excl_prefix(f1, tot1);
+        if (threadIdx.x == 0) { agg[2 * b] = tot0; agg[2 * b + 1] = tot1; }
     }
     if (STATS && stats) {
         unsigned long long a = nv, c = nt;
@@ -297,11 +387,12 @@ __device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot
 // VIRTUAL = false: thread index is the compacted slot (the reference's launch shape, used by ptk_shade).
 // VIRTUAL = true : paths are still in pre-compaction order; valid_a/agg_a from k_intersect give each hit path its slot.
 template <int MODE, bool VIRTUAL>
-__global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter, int depth, int n_arg, const int* __restrict__ d_n,
+__global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n,
                                                       PtkHits hits, PtkPaths paths, const int* __restrict__ valid_a,
                                                       const int* __restrict__ agg_a, int* __restrict__ valid_b,
                                                       int* __restrict__ agg_b, float* __restrict__ img) {
     const int n = d_n ? *d_n : n_arg;
+    const int iter = iter_ptr ? *iter_ptr : iter_arg;
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
@@ -353,9 +444,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_count(int n_arg, const int* __res
 
 __global__ void __launch_bounds__(PTK_BLOCK) k_scatter(int n_arg, const int* __restrict__ d_n, const int* __restrict__ valid,
                                                         const int* __restrict__ agg, PtkPaths pin, PtkHits hin, PtkPaths pout,
-                                                        PtkHits hout, int* __restrict__ count_out) {
+                                                        PtkHits hout, int* __restrict__ count_out, int* iter_advance, int iter_stride) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
+    // last kernel of an iteration: step the device-resident iteration number (nothing else in this kernel reads it)
+    if (iter_advance && b == 0 && threadIdx.x == 0) *iter_advance += iter_stride;
     if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0 && count_out) *count_out = 0; return; }
     const int i = b * PTK_BLOCK + threadIdx.x;
     const int flag = (i < n) ? valid[i] : 0;
@@ -387,6 +480,15 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_tonemap(const float* __restrict__
     pbo[i] = make_uchar4((unsigned char)c[0], (unsigned char)c[1], (unsigned char)c[2], 0);
 }
 
+// image = ((plane0 + plane1) + plane2) + ...  (fixed order -> deterministic)
+__global__ void __launch_bounds__(PTK_BLOCK) k_sum_planes(const float* __restrict__ planes, int n_planes, size_t plane_len, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= plane_len) return;
+    float s = planes[i];
+    for (int p = 1; p < n_planes; ++p) s += planes[(size_t)p * plane_len + i];
+    out[i] = s;
+}
+
 inline int grid_for(int n) { return (n + PTK_BLOCK - 1) / PTK_BLOCK; }
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 inline int launch_rc() { return hip_rc(hipGetLastError()); }
@@ -403,19 +505,20 @@ DevCamera to_dev_camera(const PtkCamera& c) {
 }
 
 template <bool V>
-int launch_shade(int mode, const SceneView& S, int iter, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
+int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
                  const int* va, const int* aa, int* vb, int* ab, float* img, hipStream_t st) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
-    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
-    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
 }
 
+int g_rays_per_lane = 1;               // 1: k_intersect (default), 2: k_intersect2 (two rays per lane; measured slower)
 unsigned* g_abi_queue = nullptr;       // traversal list counter + list for the kernel-level ptk_intersect entry point
 int* g_abi_list = nullptr;
 int g_abi_list_cap = 0;
@@ -439,7 +542,7 @@ int local_path_count(int W, int H, int n_parts, int part, int tile_rows) {
     return rows * W;
 }
 
-int launch_generate(const ::Camera& cam, int iter, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
+int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
                     int n_local, int* d_count0, hipStream_t st) {
     DevCamera d;
     d.W = cam.resolution.x; d.H = cam.resolution.y;
@@ -449,7 +552,7 @@ int launch_generate(const ::Camera& cam, int iter, int traceDepth, PtkPaths path
     d.right = mk3(cam.right.x, cam.right.y, cam.right.z);
     d.plx = cam.pixelLength.x; d.ply = cam.pixelLength.y;
     const int g = std::max(1, grid_for(n_local));
-    k_generate<<<g, PTK_BLOCK, 0, st>>>(d, iter, traceDepth, paths, std::max(1, n_parts), part, std::max(1, tile_rows), n_local, d_count0);
+    k_generate<<<g, PTK_BLOCK, 0, st>>>(d, iter, iter_ptr, traceDepth, paths, std::max(1, n_parts), part, std::max(1, tile_rows), n_local, d_count0);
     return launch_rc();
 }
 
@@ -461,6 +564,13 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr;
     mark(1, true);
+    if (!split && g_rays_per_lane == 2) {
+        const int g2 = (n + 2 * PTK_BLOCK - 1) / (2 * PTK_BLOCK);
+        if (stats) k_intersect2<true><<<g2, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats);
+        else k_intersect2<false><<<g2, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr);
+        mark(1, false);
+        return launch_rc();
+    }
     if (!split) {
         if (stats) k_intersect<true, false><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats, nullptr, nullptr);
         else k_intersect<false, false><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr, nullptr, nullptr);
@@ -482,7 +592,7 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
 // `capacity` bounds the launch; the live count is read from ws.counts[depth] on the device.
 static void no_mark(int, bool) {}
 int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
-                                  PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool)) {
+                                  PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce) {
     const int g = grid_for(capacity);
     if (g == 0) return 0;
     const int* d_n = ws.counts + depth;
@@ -490,19 +600,28 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
                                     ws.inline_bvh, st, mark);
     if (rc) return rc;
     mark(2, true);
-    rc = launch_shade<true>(mode, S, iter, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, st);
+    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, st);
     mark(2, false);
     if (rc) return rc;
     PtkHits none = {nullptr, nullptr, nullptr};
     mark(3, true);
-    k_scatter<<<g, PTK_BLOCK, 0, st>>>(capacity, d_n, ws.valid_b, ws.agg_b, cur, none, nxt, none, ws.counts + depth + 1);
+    k_scatter<<<g, PTK_BLOCK, 0, st>>>(capacity, d_n, ws.valid_b, ws.agg_b, cur, none, nxt, none, ws.counts + depth + 1,
+                                       last_bounce ? ws.iter_dev : nullptr, ws.iter_stride);
     mark(3, false);
     return launch_rc();
 }
 int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
-                         PtkHits hits, float* img, const Workspace& ws, hipStream_t st) {
-    return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark);
+                         PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce) {
+    return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark, last_bounce);
 }
+void set_rays_per_lane(int k) { g_rays_per_lane = (k == 2) ? 2 : 1; }
+
+int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st) {
+    const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
+    k_sum_planes<<<g, PTK_BLOCK, 0, st>>>(planes, n_planes, plane_len, out);
+    return launch_rc();
+}
+
 } // namespace ptk
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -513,7 +632,7 @@ extern "C" {
 int ptk_generate_rays(const PtkCamera* cam, int iter, int trace_depth, PtkPaths paths, void* stream) {
     if (!cam || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || cam->res[0] <= 0 || cam->res[1] <= 0) return PTK_E_BADARG;
     const int n = cam->res[0] * cam->res[1];
-    k_generate<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(to_dev_camera(*cam), iter, trace_depth, paths, 1, 0, 1, n, nullptr);
+    k_generate<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(to_dev_camera(*cam), iter, nullptr, trace_depth, paths, 1, 0, 1, n, nullptr);
     return launch_rc();
 }
 
@@ -553,7 +672,7 @@ int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkH
     }
     k_count<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg);
     int rc = launch_rc(); if (rc) return rc;
-    k_scatter<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg, paths_in, hits_in, paths_out, hits_out, d_count_out);
+    k_scatter<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg, paths_in, hits_in, paths_out, hits_out, d_count_out, nullptr, 0);
     return launch_rc();
 }
 
@@ -562,7 +681,7 @@ int ptk_shade(const PtkScene* s, int mode, int iter, int depth, int n, const int
     if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid || !img) return PTK_E_BADARG;
     if (n == 0) return 0;
-    return launch_shade<false>(mode, dev_view(*s->scene), iter, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, (hipStream_t)stream);
+    return launch_shade<false>(mode, dev_view(*s->scene), iter, nullptr, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, (hipStream_t)stream);
 }
 
 int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char* pbo, void* stream) {

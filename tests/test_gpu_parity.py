@@ -207,6 +207,54 @@ def test_tile_partition(ptk, orc, torch_cuda):
         assert total.sum() > 0
 
 
+@pytest.mark.parametrize("name,res,depth,mode,lanes", [("cornell.txt", (128, 96), 5, "MIS", 3), ("bunny_cornell.txt", (96, 96), 4, "BSDF", 4),
+                                                        ("mis_test.txt", (128, 128), 6, "MIS", 2)])
+def test_iterations_in_flight(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
+    """L iterations in flight: every iteration is computed exactly as with L = 1 (same live counts per iteration), plane l
+    sums iterations l+1, l+1+L, ..., and the image is ((plane0 + plane1) + plane2) + ... — emulated with the oracle."""
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, in_flight=lanes)
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    rays = 0
+    for it in range(1, 2 * lanes + 2):
+        r.iterate(it)
+        rr, live = o.pathtrace(m, it, planes[(it - 1) % lanes]); rays += rr
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (it, counts, live)
+    ref = planes[0].copy()
+    for p in planes[1:]:
+        ref = ref + p
+    img = r.image()
+    assert r.ray_total() == rays
+    r.close()
+    assert np.array_equal(img, ref)
+
+
+def test_graph_replay(ptk, orc, torch_cuda):
+    """hipGraph replay (device-resident iteration number) gives the same image and live counts as eager launches, with and
+    without several iterations in flight, including a jump in the iteration sequence and a sample-mode change."""
+    name, res, depth = "metallic_analytic.txt", (96, 96), 6
+    for lanes in (1, 3):
+        s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+        o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+        r = ptk.Renderer(s, ptk.MODE_MIS, in_flight=lanes, graph=True)
+        planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+        seq = [(it, ptk.MODE_MIS) for it in (1, 2, 3, 4, 5, 6, 7)] + [(20, ptk.MODE_MIS), (21, ptk.MODE_BSDF), (22, ptk.MODE_BSDF), (23, ptk.MODE_BSDF)]
+        for it, mode in seq:
+            ptk.lib.ptk_set_sample_mode(mode)
+            r.iterate(it)
+            _, live = o.pathtrace(mode, it, planes[(it - 1) % lanes])
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, live), (lanes, it, counts, live)
+        ref = planes[0].copy()
+        for p in planes[1:]:
+            ref = ref + p
+        img = r.image(); r.close()
+        assert np.array_equal(img, ref), lanes
+
+
 FULL = [  # BASELINE.json configs at full size (oracle: a few seconds per iteration)
     ("cornell.txt", None, -1, "BSDF", 2),             # configs[1]: 800x800 depth 8
     ("bunny_cornell.txt", None, -1, "BSDF", 1),       # configs[2] timed scene: 800x800 depth 8, 10k triangles
