@@ -7,11 +7,13 @@ Metric (BASELINE.json): Mrays/s = (sum over iterations and bounces of live paths
 wall time of the pathtrace() calls, on scenes/cornell.txt, 800x800, depth 8 (configs[1]; SampleMode BSDF).
 A "step" is one pathtrace() iteration (one sample per pixel) of the whole frame.
 
-N = 1 : one process, the full frame.
+N = 1 : one process, the full frame, one sample per pixel per step.
 N > 1 : launched by torch.distributed.run, one rank per GPU.  The frame is sharded into interleaved row tiles
-        (tile t of `--tile-rows` rows belongs to rank t % N; scene + BVH replicated), every rank runs its own bounce
-        loop for the K steps, then ONE RCCL reduce (sum, float32, 3*W*H) of the radiance buffer to rank 0 — inside the
-        timed region.  Total work is fixed as N grows -> "scaling": "strong".
+        (tile t of `--tile-rows` rows belongs to rank t % N; scene + BVH replicated).  Every rank runs its own bounce
+        loop on its tiles and traces N samples of them per step, so each rank launches W*H paths per step like the single
+        GPU does (per-GPU work fixed -> "scaling": "weak"; a step of the job is N samples per pixel of the whole frame).
+        After the K steps ONE RCCL reduce (sum, float32, 3*W*H) brings the radiance buffer to rank 0 — inside the timed
+        region.  `--scaling strong` keeps one sample per launch instead (per-rank launches shrink by N).
 
 Timed region: barrier + synchronize, K x ptk_pathtrace (no host synchronisation inside), [reduce], synchronize + barrier;
 time = MAX over ranks; value = rays of all ranks / time.  The scene, BVH and all state are resident in HBM before the
@@ -51,8 +53,10 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--in-flight", type=int, default=1, help="iterations in flight (ptk_set_iterations_in_flight)")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay iterations from a hipGraph")
+    ap.add_argument("--in-flight", type=int, default=3, help="iterations in flight (ptk_set_iterations_in_flight)")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay iterations from a hipGraph")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: samples per launch = N (weak) or 1 (strong)")
+    ap.add_argument("--bvh-scene", default="bunny_cornell.txt", help="second roofline measurement on a BVH scene ('' = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="ptk_set_pipeline value (A/B comparisons)")
     return ap.parse_args()
 
@@ -74,6 +78,50 @@ def cpu_baseline(scene_path, res, depth, mode, seconds):
             break
     return {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"{it} iteration(s) of the same workload ({rays} rays) in {el:.1f} s, oracle/pt_oracle.cpp, 1 thread"}
+
+
+def measure_kernels(ptk, scene, mode, pipeline, steps):
+    """Untimed diagnostic pass on ONE stream (no overlap): per-kernel device time from HIP events on the render stream, plus
+    BVH traversal statistics for scenes with triangles."""
+    r = ptk.Renderer(scene, mode, pipeline=pipeline, in_flight=1, graph=False)
+    for it in (1, 2):
+        r.iterate(it)
+    r.sync()
+    r.profile_begin()
+    rays0 = r.ray_total()
+    for it in range(3, 3 + steps):
+        r.iterate(it)
+    prof = r.profile_end()
+    rays = r.ray_total() - rays0
+    counts, _ = r.live_counts()
+    nodes = tris = rays_s = 0
+    if scene.n_triangles > 0:
+        r.traversal_stats(enable=True)
+        rays_s0 = r.ray_total()
+        r.iterate(3 + steps)
+        nodes, tris = r.traversal_stats()
+        rays_s = r.ray_total() - rays_s0
+        r.traversal_stats(enable=False)
+    r.close()
+    return prof, rays, counts, nodes, tris, rays_s
+
+
+def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps):
+    ms_int, _ = prof["intersect"]
+    has_bvh = scene.n_triangles > 0
+    bytes_per_ray = BYTES_PER_RAY_ANALYTIC + ((BYTES_PER_NODE * nodes + BYTES_PER_TRI * tris) / max(rays_s, 1) if has_bvh else 0.0)
+    achieved = rays_p * bytes_per_ray / (ms_int * 1e-3) / 1e9 if ms_int > 0 else 0.0
+    live_launches = max(int((counts > 0).sum()), 1)          # launches per iteration that had paths to process
+    return {
+        "bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / (steps * live_launches), 1),
+        "avg_launch_us": round(1e3 * ms_int / (steps * live_launches), 2),
+        "nodes_per_ray": round(nodes / max(rays_s, 1), 3) if has_bvh else 0, "tris_per_ray": round(tris / max(rays_s, 1), 3) if has_bvh else 0,
+        "note": "algorithmic bytes (SURVEY 8d) x rays / device time of k_intersect, HIP events on the render stream, %d untimed "
+                "iterations on one stream; launches with zero live paths excluded from the average; per-kernel ms/iter: %s" % (
+                    steps, {k: round(v[0] / steps, 4) for k, v in prof.items()}),
+    }
 
 
 def main():
@@ -101,8 +149,12 @@ def main():
     scene_path = os.path.join(ROOT, "scenes", a.scene)
     res = tuple(a.res) if a.res else None
     scene = ptk.Scene(scene_path, res=res, depth=a.depth)
+    # N > 1: rank r owns the row tiles t with t % N == r and traces N samples of them per launch ("weak": every rank launches
+    # W*H paths per step, exactly like the single GPU); "strong": one sample per launch (per-rank launches shrink by N).
+    weak = N > 1 and a.scaling == "weak"
+    spp = N if weak else 1
     part = (N, rank, a.tile_rows) if N > 1 else (1, 0, 1)
-    r = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph))
+    r = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), spp=spp)
     P = scene.width * scene.height
     red = torch.zeros((P, 3), dtype=torch.float32, device="cuda") if N > 1 else None
 
@@ -129,61 +181,52 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rays = r.ray_total() - rays0
+    counts, traced = r.live_counts()
+    r.close()
     if N > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
         q = torch.tensor([rays], dtype=torch.int64, device="cuda"); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
 
-    # ---- untimed: per-kernel device time (HIP events on the render stream) + traversal statistics ----
-    r.profile_begin()
-    rays_p0 = r.ray_total()
-    for _ in range(a.profile_steps):
-        it += 1; r.iterate(it)
-    prof = r.profile_end()
-    rays_p = r.ray_total() - rays_p0
-    counts, traced = r.live_counts()
-    nodes = tris = rays_s = 0
-    if scene.n_triangles > 0:          # BVH scenes: mean node visits / triangle tests per ray (instrumented kernel, separate pass)
-        r.traversal_stats(enable=True)
-        rays_s0 = r.ray_total()
-        it += 1; r.iterate(it)
-        nodes, tris = r.traversal_stats()
-        rays_s = r.ray_total() - rays_s0
-        r.traversal_stats(enable=False)
-    r.close()
-
     if rank == 0:
-        ms_int, n_int = prof["intersect"]
-        has_bvh = scene.n_triangles > 0
-        bytes_per_ray = BYTES_PER_RAY_ANALYTIC + (BYTES_PER_NODE * nodes / max(rays_s, 1) + BYTES_PER_TRI * tris / max(rays_s, 1) if has_bvh else 0.0)
-        achieved = rays_p * bytes_per_ray / (ms_int * 1e-3) / 1e9 if ms_int > 0 else 0.0
-        live_launches = int((counts > 0).sum())         # launches that had paths to process, per iteration
-        roofline = {
-            "bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / max(a.profile_steps * max(live_launches, 1), 1), 1),
-            "avg_launch_us": round(1e3 * ms_int / max(a.profile_steps * max(live_launches, 1), 1), 2),
-            "nodes_per_ray": round(nodes / max(rays_s, 1), 3) if has_bvh else 0, "tris_per_ray": round(tris / max(rays_s, 1), 3) if has_bvh else 0,
-            "note": "device time of k_intersect from HIP events on the render stream over %d untimed iterations; launches with zero live "
-                    "paths excluded from the average; per-kernel split ms/iter: %s" % (
-                        a.profile_steps, {k: round(v[0] / a.profile_steps, 4) for k, v in prof.items()}),
-        }
+        prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
+        roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps)
+        extra = {}
+        if N == 1 and a.bvh_scene and a.bvh_scene != a.scene:
+            # the HBM-fraction target is only meaningful where the kernel streams BVH data: same measurement
+            # on the BASELINE configs[2] timed scene (bunny_cornell.txt, 800x800 depth 8)
+            bs = ptk.Scene(os.path.join(ROOT, "scenes", a.bvh_scene))
+            rb = ptk.Renderer(bs, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph))
+            for i in range(1, 5):
+                rb.iterate(i)
+            rb.sync(); rb0 = rb.ray_total(); rb.timer_start()
+            for i in range(5, 5 + 24):
+                rb.iterate(i)
+            bms = rb.timer_stop(); brays = rb.ray_total() - rb0
+            rb.close()
+            pb = measure_kernels(ptk, bs, mode, a.pipeline, a.profile_steps)
+            extra["roofline_bvh_scene"] = dict(roofline_of(bs, *pb, a.profile_steps), workload=f"scenes/{a.bvh_scene} {bs.width}x{bs.height} depth {bs.trace_depth}",
+                                               mrays_per_s=round(brays / bms / 1e3, 1))
         cpu = None
         if N == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(scene_path, res, a.depth, mode, a.cpu_seconds)
         out = {
             "metric": "Mrays/s (paths x bounces / s)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (weak or N == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scenes/{a.scene} {scene.width}x{scene.height} depth {scene.trace_depth}, SampleMode {a.mode.upper()}"
                                    + (" (BASELINE configs[1])" if a.scene == "cornell.txt" and res is None and a.depth < 0 and a.mode == "bsdf" else ""),
-                       "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce": [int(c) for c in counts],
-                       "sharding": "none" if N == 1 else f"interleaved row tiles of {a.tile_rows} rows, tile %% {N} == rank, one RCCL reduce of the radiance buffer",
-                       "pipeline": "staged (intersect / shade / scatter per bounce, device-resident counts)"},
+                       "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce_last_step_rank0": [int(c) for c in counts],
+                       "sharding": "none" if N == 1 else (f"interleaved row tiles of {a.tile_rows} rows (tile %% {N} == rank), {spp} sample(s) of the owned "
+                                                          f"pixels per launch, one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
+                       "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
+                       "pipeline": "staged: intersect / shade / scatter per bounce, device-resident counts, no host sync"},
             "device_ms_per_step": round(dev_ms / a.steps, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out.update(extra)
         print(json.dumps(out))
     if N > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -149,6 +149,12 @@ int ptk_get_sample_mode(void);
  * iteration is computed exactly as with L = 1; only the order of the per-pixel additions changes: plane l sums
  * iterations l+1, l+1+L, ... and the image is ((plane0 + plane1) + plane2) + ...  Not a reference feature. */
 int ptk_set_iterations_in_flight(int lanes);
+/* Samples per launch (1..64, default 1; set before ptk_pathtrace_init).  With spp > 1, ptk_pathtrace(.., step) traces
+ * iterations (step-1)*spp + 1 .. step*spp of the owned pixels in one set of launches: camera jitter is keyed per iteration
+ * as usual, the shading RNG by (first iteration of the batch, compacted slot, depth), and every sample accumulates into its
+ * own radiance plane; the image is the sum of the planes in order.  Used with the tile partition so that a rank that owns
+ * 1/N of the pixels still launches full-size kernels (multi-GPU weak scaling).  Not a reference feature. */
+int ptk_set_samples_per_launch(int spp);
 /* 1: replay every iteration from a hipGraph captured once per lane (the kernels then read the iteration number from device
  * memory); 0 (default): launch the kernels one by one.  Identical results; cuts the host cost per iteration. */
 int ptk_set_graph_replay(int on);

@@ -838,6 +838,13 @@ static void lightSample(const OrcScene& S, v3 viewPos, Rng rng, LightRec& rec) {
 // ---------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------
+// Radiance address of a path.  Reference: img[pixelIndex].  The build's "samples per launch" extension (not a reference
+// feature) carries the sample number in bits 24..30 of pixelIndex and gives every sample its own plane of g_plane_stride
+// floats; with spp = 1 the high bits are zero and this is the reference's address.
+static size_t g_plane_stride = 0;
+static inline float* radiance_px(float* img, int pixelIndex) {
+    return img + (size_t)(pixelIndex >> 24) * g_plane_stride + 3 * (size_t)(pixelIndex & 0xFFFFFF);
+}
 // pathtrace.cu:135-163
 static void generate_ray(const Camera& cam, int iter, int traceDepth, int x, int y, PathSegment& seg) {
     seg.o = cam.position;
@@ -873,7 +880,7 @@ static int shade_bsdf(const OrcScene& S, int iter, int idx, int depth, const Ise
         ps.color = ps.color * (srec.bsdf / srec.pdf);
         ps.remainingBounces = 0;
         v3 c = processNAN(ps.color);
-        float* px = img + 3 * ps.pixelIndex; px[0] += c.x; px[1] += c.y; px[2] += c.z;
+        float* px = radiance_px(img, ps.pixelIndex); px[0] += c.x; px[1] += c.y; px[2] += c.z;
         return 0;
     }
     shade_continue(ps, is, srec, m.type, valid);
@@ -891,7 +898,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     v3 viewPos = is.p, viewNor = is.n;
-    float* px = img + 3 * ps.pixelIndex;
+    float* px = radiance_px(img, ps.pixelIndex);
     if (srec.pdf == 0) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
     if (m.type == MAT_LIGHT) {
         float weight = 1.f;
@@ -925,7 +932,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
 static int shade_direct(const OrcScene& S, int iter, int idx, int depth, const Isect& is, PathSegment& ps, float* img) {
     Rng rng = make_rng(iter, idx, depth);
     const Material& m = S.materials[is.materialId];
-    float* px = img + 3 * ps.pixelIndex;
+    float* px = radiance_px(img, ps.pixelIndex);
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
     if (m.type == MAT_LIGHT) {
         ps.color = ps.color * v3(m.albedo[0], m.albedo[1], m.albedo[2]);
@@ -1432,16 +1439,24 @@ int orc_compact(int n, const int* valid, void* paths, void* isects) {
 // timing[4] (optional, seconds): generate, intersect, shade, compact.
 // Tile partition (the build's multi-GPU sharding; (1,0,1) = the reference's full frame): only the pixels of
 // rows with ((y / tile_rows) % n_parts) == part are traced, enumerated in row-major order of the owned rows.
-long long orc_pathtrace_tiled(OrcScene* S, int mode, int iter, int n_parts, int part, int tile_rows, float* img, int* live, double* timing) {
+// spp > 1 (the build's samples-per-launch extension): launch `step` traces iterations (step-1)*spp + s + 1, s = 0..spp-1, of the
+// owned pixels together: path order is sample-major, camera keys use the sample's own iteration number, shading keys use the
+// batch's first iteration, and img must hold spp planes of 3*P floats (sample s accumulates into plane s).
+long long orc_pathtrace_batch(OrcScene* S, int mode, int step, int spp, int n_parts, int part, int tile_rows, float* img, int* live, double* timing) {
     const Camera& cam = S->cam;
     int W = cam.res[0], H = cam.res[1];
-    std::vector<PathSegment> paths; paths.reserve((size_t)W * H / n_parts + W * tile_rows);
+    g_plane_stride = 3 * (size_t)W * H;
+    std::vector<PathSegment> paths; paths.reserve((size_t)W * H * spp / n_parts + W * tile_rows);
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    for (int y = 0; y < H; ++y) {
-        if (((y / tile_rows) % n_parts) != part) continue;
-        for (int x = 0; x < W; ++x) { PathSegment ps; generate_ray(cam, iter, S->traceDepth, x, y, ps); paths.push_back(ps); }
+    for (int s = 0; s < spp; ++s) {
+        const int iter = (step - 1) * spp + s + 1;
+        for (int y = 0; y < H; ++y) {
+            if (((y / tile_rows) % n_parts) != part) continue;
+            for (int x = 0; x < W; ++x) { PathSegment ps; generate_ray(cam, iter, S->traceDepth, x, y, ps); ps.pixelIndex |= (s << 24); paths.push_back(ps); }
+        }
     }
+    const int key_iter = (step - 1) * spp + 1;
     int P = (int)paths.size();
     std::vector<Isect> isects(P); std::vector<int> valid(P);
     auto t1 = clk::now();
@@ -1456,7 +1471,7 @@ long long orc_pathtrace_tiled(OrcScene* S, int mode, int iter, int n_parts, int 
         auto b = clk::now();
         n = orc_compact(n, valid.data(), paths.data(), isects.data());
         auto c = clk::now();
-        orc_shade(S, mode, iter, depth, n, isects.data(), paths.data(), valid.data(), img);
+        orc_shade(S, mode, key_iter, depth, n, isects.data(), paths.data(), valid.data(), img);
         auto d2 = clk::now();
         n = orc_compact(n, valid.data(), paths.data(), isects.data());
         auto e = clk::now();
@@ -1467,6 +1482,9 @@ long long orc_pathtrace_tiled(OrcScene* S, int mode, int iter, int n_parts, int 
     }
     if (timing) { timing[0] += tg; timing[1] += ti; timing[2] += ts; timing[3] += tc; }
     return rays;
+}
+long long orc_pathtrace_tiled(OrcScene* S, int mode, int iter, int n_parts, int part, int tile_rows, float* img, int* live, double* timing) {
+    return orc_pathtrace_batch(S, mode, iter, 1, n_parts, part, tile_rows, img, live, timing);
 }
 long long orc_pathtrace(OrcScene* S, int mode, int iter, float* img, int* live, double* timing) {
     return orc_pathtrace_tiled(S, mode, iter, 1, 0, 1, img, live, timing);

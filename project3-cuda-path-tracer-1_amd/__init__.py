@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
-    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay",
+    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch",
 ]
 
 
@@ -126,6 +126,7 @@ def _load() -> C.CDLL:
     lib.ptk_set_pipeline.argtypes = [ci]
     lib.ptk_set_iterations_in_flight.argtypes = [ci]
     lib.ptk_set_graph_replay.argtypes = [ci]
+    lib.ptk_set_samples_per_launch.argtypes = [ci]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
     lib.ptk_profile_end.argtypes = [vp, vp]
     lib.ptk_enable_traversal_stats.argtypes = [ci]
@@ -259,9 +260,10 @@ class Renderer:
     """File-static render context of the library (one at a time, like the reference)."""
 
     def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1), pipeline: int = 0, in_flight: int = 1,
-                 graph: bool = False):
+                 graph: bool = False, spp: int = 1):
         self.scene = scene
         lib.ptk_pathtrace_free()
+        _chk(lib.ptk_set_samples_per_launch(spp), "ptk_set_samples_per_launch")
         _chk(lib.ptk_set_graph_replay(1 if graph else 0), "ptk_set_graph_replay")
         _chk(lib.ptk_set_iterations_in_flight(in_flight), "ptk_set_iterations_in_flight")
         _chk(lib.ptk_set_pipeline(pipeline), "ptk_set_pipeline")
@@ -287,6 +289,7 @@ class Renderer:
         _chk(lib.ptk_copy_image_to_device(_ptr(tensor)), "ptk_copy_image_to_device")
 
     def live_counts(self):
+        """per-bounce live-path counts of the LAST iterate() call (all samples of a batched launch together)"""
         c = np.zeros(self.scene.trace_depth + 1, np.int32)
         d = C.c_int(0)
         _chk(lib.ptk_get_live_counts(c.ctypes.data, C.byref(d)), "ptk_get_live_counts")
@@ -327,3 +330,4 @@ class Renderer:
         lib.ptk_set_tile_partition(1, 0, 1)
         lib.ptk_set_iterations_in_flight(1)
         lib.ptk_set_graph_replay(0)
+        lib.ptk_set_samples_per_launch(1)

@@ -53,7 +53,7 @@ struct RenderContext {
     unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
     int n_parts = 1, part = 0, tile_rows = 1;
-    int pipeline = 0, n_lanes = 1;
+    int pipeline = 0, n_lanes = 1, spp = 1, n_pix = 0;
     bool use_graph = false;
     int last_lane = 0;
     bool live = false;
@@ -106,7 +106,9 @@ int lane_init(Lane& l, int idx) {
     hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
-    l.plane = g.planes + (size_t)idx * 3 * (size_t)g.P;
+    l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
+    l.ws.plane_stride = 3u * (unsigned)g.P;
+    l.ws.spp = g.spp;
     if ((rc = alloc_paths(l.bufA, g.capacity))) return rc;
     if ((rc = alloc_paths(l.bufB, g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
@@ -139,15 +141,18 @@ int context_init(Scene* scene) {
     g.P = cam.resolution.x * cam.resolution.y;
     g.traceDepth = scene->state.traceDepth;
     if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
-    g.capacity = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
+    g.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
+    g.capacity = g.n_pix * g.spp;
+    if (g.P >= (1 << 24)) return PTK_E_BADARG;            // pixelIndex carries the sample plane in bits 24..30
     int rc;
     hipError_t e;
     if ((e = hipEventCreate(&g.ev0)) != hipSuccess) return (int)e;
     if ((e = hipEventCreate(&g.ev1)) != hipSuccess) return (int)e;
     const size_t plane = 3 * (size_t)g.P;
-    if ((rc = dalloc(&g.planes, plane * g.n_lanes))) return rc;
-    if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * g.n_lanes)) != hipSuccess) return (int)e;
-    if (g.n_lanes > 1) { if ((rc = dalloc(&g.image, plane))) return rc; } else g.image = g.planes;
+    const size_t n_planes = (size_t)g.n_lanes * g.spp;
+    if ((rc = dalloc(&g.planes, plane * n_planes))) return rc;
+    if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * n_planes)) != hipSuccess) return (int)e;
+    if (n_planes > 1) { if ((rc = dalloc(&g.image, plane))) return rc; } else g.image = g.planes;
     if ((rc = dalloc(&g.ray_total, 1))) return rc;
     if ((e = hipMemset(g.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return (int)e;
     g.lanes.assign(g.n_lanes, Lane());
@@ -183,7 +188,7 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
     ws.iter_stride = g.n_lanes;
     prof_mark(0, true);
-    int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, g.n_parts, g.part, g.tile_rows, g.capacity, ws.counts, L.stream);
+    int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, g.n_parts, g.part, g.tile_rows, g.n_pix, g.spp, ws.counts, L.stream);
     prof_mark(0, false);
     if (rc) return rc;
     PtkPaths cur = L.bufA, nxt = L.bufB;
@@ -251,7 +256,7 @@ int join_on_lane0() {
 int resolve_image() {
     int rc = join_on_lane0();
     if (rc) return rc;
-    if (g.n_lanes > 1) rc = launch_sum_planes(g.planes, g.n_lanes, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
+    if (g.n_lanes * g.spp > 1) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
     return rc;
 }
 
@@ -275,7 +280,7 @@ int ptk_pathtrace(unsigned char* pbo, int frame, int iter) {
     if (rc || !pbo) return rc;
     if ((rc = resolve_image())) return rc;
     const Camera& cam = g.scene->state.camera;
-    return ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter, pbo, g.lanes[0].stream);
+    return ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter * g.spp, pbo, g.lanes[0].stream);
 }
 
 int ptk_set_sample_mode(int mode) { if (mode < 0 || mode > 2) return PTK_E_BADARG; g_mode_override = mode; return 0; }
@@ -289,6 +294,15 @@ int ptk_set_iterations_in_flight(int lanes) {
 
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
 int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
+
+/* Samples per launch (1..64, default 1; set before ptk_pathtrace_init): ptk_pathtrace(.., step) then traces iterations
+ * (step-1)*spp + 1 .. step*spp of the owned pixels in ONE set of launches (camera jitter keyed per iteration as usual, shading
+ * RNG keyed by the batch's first iteration and the compacted slot, one radiance plane per sample). */
+int ptk_set_samples_per_launch(int spp) {
+    if (spp < 1 || spp > 64 || g.live) return PTK_E_BADARG;
+    g.spp = spp;
+    return 0;
+}
 
 int ptk_get_image(float* host_out) {
     if (!g.live) return PTK_E_NOSCENE;

@@ -38,12 +38,14 @@ struct Workspace {               // per-render-context scratch, device memory
     int* list = nullptr;         // the work list [capacity]
     int* iter_dev = nullptr;     // device-resident iteration number (hipGraph replay); null = use the launch argument
     int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
+    unsigned plane_stride = 0;   // floats per radiance plane (3*P)
+    int spp = 1;                 // samples (iterations) per launch
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     int capacity = 0;
 };
 
 int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
-                    int n_local, int* d_count0, hipStream_t st);
+                    int n_pix, int spp, int* d_count0, hipStream_t st);
 int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
                          PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce);
 int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,

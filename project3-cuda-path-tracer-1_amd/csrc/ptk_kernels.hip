@@ -67,20 +67,26 @@ struct DevCamera { int W, H; f3 pos, view, up, right; float plx, ply; };
 // ------------------------------------------------------------------------------------------------------------------
 // generateRayFromCamera, pathtrace.cu:135-163.  Path j -> pixel (x,y) through the tile partition.
 // ------------------------------------------------------------------------------------------------------------------
+// Samples per launch (spp > 1, not a reference feature): launch `step` traces iterations (step-1)*spp + s + 1, s = 0..spp-1,
+// of the owned pixels at once; path j = s * n_pix + (pixel slot), and the sample index rides in bits 24..30 of pixelIndex so
+// that each sample accumulates into its own radiance plane (two samples of one pixel may be shaded concurrently).
 __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_arg, const int* __restrict__ iter_ptr, int traceDepth,
-                                                         PtkPaths paths, int n_parts, int part, int tile_rows, int n_local, int* count0) {
-    const int iter = iter_ptr ? *iter_ptr : iter_arg;      // device-resident iteration number when replayed from a hipGraph
+                                                         PtkPaths paths, int n_parts, int part, int tile_rows, int n_pix, int spp, int* count0) {
+    const int step = iter_ptr ? *iter_ptr : iter_arg;      // device-resident iteration number when replayed from a hipGraph
+    const int n_local = n_pix * spp;
     const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (j == 0 && count0) *count0 = n_local;
     if (j >= n_local) return;
-    const int lr = j / cam.W, x = j - lr * cam.W;
+    const int s = j / n_pix, jp = j - s * n_pix;
+    const int iter = (step - 1) * spp + s + 1;
+    const int lr = jp / cam.W, x = jp - lr * cam.W;
     const int y = ((lr / tile_rows) * n_parts + part) * tile_rows + (lr % tile_rows);
     Rng rng = make_rng(x, y, iter);                       // argument order of pathtrace.cu:148: (iter:=x, index:=y, depth:=iter)
     const f2 r = sample2D(rng);
     const float fx = static_cast<float>(static_cast<float>(x) + ((double)r.x - 0.5) - cam.W * 0.5f);
     const float fy = static_cast<float>(static_cast<float>(y) + ((double)r.y - 0.5) - cam.H * 0.5f);
     const f3 d = normalize(cam.view - cam.right * cam.plx * fx - cam.up * cam.ply * fy);
-    st4(paths.o_pix, j, make_float4(cam.pos.x, cam.pos.y, cam.pos.z, __int_as_float(x + y * cam.W)));
+    st4(paths.o_pix, j, make_float4(cam.pos.x, cam.pos.y, cam.pos.z, __int_as_float((s << 24) | (x + y * cam.W))));
     st4(paths.d_bnc, j, make_float4(d.x, d.y, d.z, __int_as_float(traceDepth)));
     st4(paths.col_pdf, j, make_float4(1.f, 1.f, 1.f, -1.f));
 }
@@ -320,13 +326,15 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
 // ------------------------------------------------------------------------------------------------------------------
 struct PathRegs { f3 o, d, col; int pix, bounces; float prevPdf; };
 
-__device__ __forceinline__ void add_radiance(float* __restrict__ img, int pix, f3 c) {
-    float* p = img + 3 * (size_t)pix;          // one live path per pixel: plain read-modify-write, no atomics
+struct Film { float* img; unsigned plane_stride; };       // radiance planes: float[plane][3*P]
+__device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
+    // one live path per (sample plane, pixel): plain read-modify-write, no atomics.  plane = pix >> 24 (0 unless spp > 1)
+    float* p = film.img + (size_t)(pix >> 24) * film.plane_stride + 3 * (size_t)(pix & 0xFFFFFF);
     p[0] += c.x; p[1] += c.y; p[2] += c.z;
 }
 
 template <int MODE>
-__device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot, int depth, const Hit& h, PathRegs& p, float* __restrict__ img) {
+__device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
     if (h.t <= 0.f) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
     const DevMaterial& m = S.mats[h.mat];
     Rng rng = make_rng(iter, slot, depth);
@@ -390,9 +398,10 @@ template <int MODE, bool VIRTUAL>
 __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n,
                                                       PtkHits hits, PtkPaths paths, const int* __restrict__ valid_a,
                                                       const int* __restrict__ agg_a, int* __restrict__ valid_b,
-                                                      int* __restrict__ agg_b, float* __restrict__ img) {
+                                                      int* __restrict__ agg_b, float* __restrict__ img_base, unsigned plane_stride, int spp) {
     const int n = d_n ? *d_n : n_arg;
-    const int iter = iter_ptr ? *iter_ptr : iter_arg;
+    const int iter = ((iter_ptr ? *iter_ptr : iter_arg) - 1) * spp + 1;     // RNG key: first iteration of this launch's batch
+    const Film img = {img_base, plane_stride};
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
@@ -506,13 +515,13 @@ DevCamera to_dev_camera(const PtkCamera& c) {
 
 template <bool V>
 int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                 const int* va, const int* aa, int* vb, int* ab, float* img, hipStream_t st) {
+                 const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
-    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
-    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img); break;
+    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -543,7 +552,7 @@ int local_path_count(int W, int H, int n_parts, int part, int tile_rows) {
 }
 
 int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int traceDepth, PtkPaths paths, int n_parts, int part, int tile_rows,
-                    int n_local, int* d_count0, hipStream_t st) {
+                    int n_pix, int spp, int* d_count0, hipStream_t st) {
     DevCamera d;
     d.W = cam.resolution.x; d.H = cam.resolution.y;
     d.pos = mk3(cam.position.x, cam.position.y, cam.position.z);
@@ -551,8 +560,8 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
     d.up = mk3(cam.up.x, cam.up.y, cam.up.z);
     d.right = mk3(cam.right.x, cam.right.y, cam.right.z);
     d.plx = cam.pixelLength.x; d.ply = cam.pixelLength.y;
-    const int g = std::max(1, grid_for(n_local));
-    k_generate<<<g, PTK_BLOCK, 0, st>>>(d, iter, iter_ptr, traceDepth, paths, std::max(1, n_parts), part, std::max(1, tile_rows), n_local, d_count0);
+    const int g = std::max(1, grid_for(n_pix * spp));
+    k_generate<<<g, PTK_BLOCK, 0, st>>>(d, iter, iter_ptr, traceDepth, paths, std::max(1, n_parts), part, std::max(1, tile_rows), n_pix, spp, d_count0);
     return launch_rc();
 }
 
@@ -600,7 +609,7 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
                                     ws.inline_bvh, st, mark);
     if (rc) return rc;
     mark(2, true);
-    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, st);
+    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, st);
     mark(2, false);
     if (rc) return rc;
     PtkHits none = {nullptr, nullptr, nullptr};
@@ -632,7 +641,7 @@ extern "C" {
 int ptk_generate_rays(const PtkCamera* cam, int iter, int trace_depth, PtkPaths paths, void* stream) {
     if (!cam || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || cam->res[0] <= 0 || cam->res[1] <= 0) return PTK_E_BADARG;
     const int n = cam->res[0] * cam->res[1];
-    k_generate<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(to_dev_camera(*cam), iter, nullptr, trace_depth, paths, 1, 0, 1, n, nullptr);
+    k_generate<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(to_dev_camera(*cam), iter, nullptr, trace_depth, paths, 1, 0, 1, n, 1, nullptr);
     return launch_rc();
 }
 
@@ -681,7 +690,7 @@ int ptk_shade(const PtkScene* s, int mode, int iter, int depth, int n, const int
     if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid || !img) return PTK_E_BADARG;
     if (n == 0) return 0;
-    return launch_shade<false>(mode, dev_view(*s->scene), iter, nullptr, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, (hipStream_t)stream);
+    return launch_shade<false>(mode, dev_view(*s->scene), iter, nullptr, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, 0u, 1, (hipStream_t)stream);
 }
 
 int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char* pbo, void* stream) {

@@ -59,6 +59,7 @@ L.orc_shade.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
 L.orc_compact.restype = ci; L.orc_compact.argtypes = [ci, vp, vp, vp]
 L.orc_pathtrace.restype = C.c_longlong; L.orc_pathtrace.argtypes = [vp, ci, ci, vp, vp, vp]
 L.orc_pathtrace_tiled.restype = C.c_longlong; L.orc_pathtrace_tiled.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp]
+L.orc_pathtrace_batch.restype = C.c_longlong; L.orc_pathtrace_batch.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
 L.orc_stats.argtypes = [vp, ci]
 L.orc_tonemap.argtypes = [vp, ci, ci, vp]
 L.orc_set_trig_mode.argtypes = [ci]
@@ -118,6 +119,13 @@ class Scene:
         live = np.zeros(self.trace_depth + 1, np.int32)
         rays = L.orc_pathtrace_tiled(self.h, mode, it, partition[0], partition[1], partition[2], img.ctypes.data, live.ctypes.data,
                                      timing.ctypes.data if timing is not None else None)
+        return int(rays), live
+
+    def pathtrace_batch(self, mode, step, spp, planes, partition=(1, 0, 1)):
+        """planes: float32 [spp, P, 3] contiguous; sample s of the launch accumulates into planes[s]"""
+        assert planes.flags.c_contiguous and planes.shape == (spp, self.P, 3)
+        live = np.zeros(self.trace_depth + 1, np.int32)
+        rays = L.orc_pathtrace_batch(self.h, mode, step, spp, partition[0], partition[1], partition[2], planes.ctypes.data, live.ctypes.data, None)
         return int(rays), live
 
     def close(self):

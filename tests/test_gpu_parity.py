@@ -232,6 +232,36 @@ def test_iterations_in_flight(ptk, orc, torch_cuda, name, res, depth, mode, lane
     assert np.array_equal(img, ref)
 
 
+@pytest.mark.parametrize("name,res,depth,mode,spp,part,lanes", [
+    ("cornell.txt", (96, 64), 5, "MIS", 4, (1, 0, 1), 1),
+    ("cornell.txt", (96, 80), 4, "BSDF", 2, (2, 1, 8), 1),          # the multi-GPU configuration: tiles x samples
+    ("bunny_cornell.txt", (64, 64), 4, "BSDF", 3, (3, 2, 4), 2),    # ... with iterations in flight on top
+])
+def test_samples_per_launch(ptk, orc, torch_cuda, name, res, depth, mode, spp, part, lanes):
+    """spp iterations of the owned pixels traced in one set of launches, one radiance plane per sample, against the oracle's
+    restatement of the same batching (sample-major path order, per-iteration camera keys, batch-keyed shading RNG)."""
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, partition=part, in_flight=lanes, spp=spp)
+    planes = np.zeros((lanes, spp, o.P, 3), np.float32)
+    rays = 0
+    for step in range(1, 2 * lanes + 2):
+        r.iterate(step)
+        rr, live = o.pathtrace_batch(m, step, spp, planes[(step - 1) % lanes], partition=part); rays += rr
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (step, counts, live)
+    flat = planes.reshape(lanes * spp, o.P, 3)
+    ref = flat[0].copy()
+    for p in flat[1:]:
+        ref = ref + p
+    img = r.image()
+    assert r.ray_total() == rays
+    r.close()
+    assert np.array_equal(img, ref)
+    assert ref.sum() > 0
+
+
 def test_graph_replay(ptk, orc, torch_cuda):
     """hipGraph replay (device-resident iteration number) gives the same image and live counts as eager launches, with and
     without several iterations in flight, including a jump in the iteration sequence and a sample-mode change."""
