@@ -292,6 +292,9 @@ int ptk_set_iterations_in_flight(int lanes) {
     return 0;
 }
 
+/* Shading kernel layout: 0 = one path per thread in path order; 256 / 512 / 1024 = paths of a block of that many consecutive
+ * paths are counting-sorted by material type before shading (default 256).  Identical results. */
+int ptk_set_shade_binning(int block) { if (block != 0 && block != 256 && block != 512 && block != 1024) return PTK_E_BADARG; set_shade_bin(block); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
 int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
 

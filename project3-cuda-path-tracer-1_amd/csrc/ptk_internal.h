@@ -51,6 +51,7 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
 int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
                                   PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce);
 void set_rays_per_lane(int k);
+void set_shade_bin(int nt);
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);
 

@@ -437,6 +437,99 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
     }
 }
 
+// Material-binned shading (pipeline default).  The BSDF switch of Material::scatterSample is the divergent part of shading
+// (Lambertian ~350, Microfacet ~600, Dielectric ~250, Light ~50 VALU; a wave with a mix executes them all).  A block of NT
+// consecutive paths is counting-sorted by material type in LDS and thread j shades the j-th path of that order, so most waves
+// see one type.  Each path keeps its own compacted slot (the RNG key), hit and state, so results are unchanged; only which
+// lane does the work moves (within the block's contiguous NT-path window, so global accesses stay line-coalesced).
+template <int MODE, int NT>
+__global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+                                                      const int* __restrict__ d_n, PtkHits hits, PtkPaths paths,
+                                                      const int* __restrict__ valid_a, const int* __restrict__ agg_a,
+                                                      int* __restrict__ valid_b, int* __restrict__ agg_b,
+                                                      float* __restrict__ img_base, unsigned plane_stride, int spp) {
+    constexpr int NW = NT / 64, NKEY = 6, SUB = NT / PTK_BLOCK;      // SUB aggregate entries (256-path ranges) per block
+    __shared__ int s_cnt[NW][NKEY];
+    __shared__ int s_perm[NT];
+    __shared__ int s_slot[NT];
+    __shared__ int s_red[NW];
+    const int n = d_n ? *d_n : n_arg;
+    const int iter = ((iter_ptr ? *iter_ptr : iter_arg) - 1) * spp + 1;
+    const Film img = {img_base, plane_stride};
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (b * NT >= n) return;
+    const int i = b * NT + tid;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // --- original order: flag, compacted slot, material key
+    const int flag = (i < n) ? valid_a[i] : 0;
+    int key = NKEY - 1;
+    if (flag) key = S.mats[__float_as_int(hits.p_mat[4 * (size_t)i + 3])].type;
+    unsigned long long bal[NKEY];
+#pragma unroll
+    for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
+    if (lane < NKEY) s_cnt[wid][lane] = __popcll(bal[lane]);
+    // prior hit count of all earlier 256-path ranges (agg_a is indexed by 256-path range)
+    int prior = 0;
+    for (int k = tid; k < b * SUB; k += NT) prior += agg_a[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o, 64);
+    if (lane == 0) s_red[wid] = prior;
+    __syncthreads();
+    prior = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) prior += s_red[w];
+    // rank in the hit order (keys 0..4 are hits) and in the sorted order
+    int hits_before = 0, rank = 0, n_active = 0;
+#pragma unroll
+    for (int k = 0; k < NKEY; ++k) {
+        int before_waves = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = s_cnt[w][k]; before_waves += (w < wid) ? c : 0; total += c; }
+        if (k < NKEY - 1) { hits_before += before_waves + __popcll(bal[k] & lt); n_active += total; }
+        if (key == k) rank += before_waves + __popcll(bal[k] & lt);
+        else if (key > k) rank += total;
+    }
+    s_perm[rank] = tid;
+    s_slot[tid] = prior + hits_before;
+    __syncthreads();
+    // --- sorted order: thread `tid` shades item src
+    int alive = 0, src = -1;
+    if (tid < n_active) {
+        src = s_perm[tid];
+        const int it = b * NT + src;
+        const int slot = s_slot[src];
+        const float4 h0 = ld4(hits.t_n, it), h1 = ld4(hits.p_mat, it), h2 = ld4(hits.uv_ids, it);
+        const float4 o4 = ld4(paths.o_pix, it), d4 = ld4(paths.d_bnc, it), c4 = ld4(paths.col_pdf, it);
+        Hit h;
+        h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+        h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
+        PathRegs p;
+        p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+        p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+        p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+        alive = shade_path<MODE>(S, iter, slot, depth, h, p, img);
+        st4(paths.o_pix, it, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+        st4(paths.d_bnc, it, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+        st4(paths.col_pdf, it, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+    }
+    __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
+    s_slot[tid] = 0;
+    __syncthreads();
+    if (src >= 0) s_slot[src] = alive;
+    __syncthreads();
+    const int alive_here = s_slot[tid];
+    if (i < n) valid_b[i] = alive_here;
+    const unsigned long long ab = __ballot(alive_here != 0);
+    if (lane == 0) s_red[wid] = __popcll(ab);
+    __syncthreads();
+    if (tid < SUB && (b * SUB + tid) * PTK_BLOCK < n) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < PTK_WAVES; ++w) t += s_red[tid * PTK_WAVES + w];
+        agg_b[b * SUB + tid] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // compact_rays, pathtrace.cu:614-631: k_count (per-block aggregates) + k_scatter (stable scatter, device count out)
 // ------------------------------------------------------------------------------------------------------------------
@@ -513,9 +606,28 @@ DevCamera to_dev_camera(const PtkCamera& c) {
     return d;
 }
 
+int g_shade_bin = 256;                 // 0: plain k_shade; 256/512/1024: k_shade_binned block size (paths sorted by material)
+
+template <int NT>
+int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
+                        const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st) {
+    const int g = (n + NT - 1) / NT;
+    if (g == 0) return 0;
+    switch (mode) {
+    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    default: return PTK_E_BADARG;
+    }
+    return launch_rc();
+}
+
 template <bool V>
 int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
                  const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st) {
+    if (V && g_shade_bin == 1024) return launch_shade_binned<1024>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st);
+    if (V && g_shade_bin == 512) return launch_shade_binned<512>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st);
+    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st);
     const int g = grid_for(n);
     if (g == 0) return 0;
     switch (mode) {
@@ -624,6 +736,7 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
     return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark, last_bounce);
 }
 void set_rays_per_lane(int k) { g_rays_per_lane = (k == 2) ? 2 : 1; }
+void set_shade_bin(int nt) { g_shade_bin = (nt == 256 || nt == 512 || nt == 1024) ? nt : 0; }
 
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st) {
     const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
