@@ -106,7 +106,17 @@ def measure_kernels(ptk, scene, mode, pipeline, steps):
     return prof, rays, counts, nodes, tris, rays_s
 
 
-def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps):
+def pmc_traffic(scene_file):
+    """HBM bytes per k_intersect launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, one
+    counter per pass; profiles/r1_pmc_traffic.json says how they were taken).  PMC collection cannot run inside this process."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["scenes"].get(scene_file)
+        return d["traffic_bytes_per_launch"] if d else None
+    except Exception:
+        return None
+
+
+def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_file=None):
     ms_int, _ = prof["intersect"]
     has_bvh = scene.n_triangles > 0
     bytes_per_ray = BYTES_PER_RAY_ANALYTIC + ((BYTES_PER_NODE * nodes + BYTES_PER_TRI * tris) / max(rays_s, 1) if has_bvh else 0.0)
@@ -114,7 +124,9 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps):
     live_launches = max(int((counts > 0).sum()), 1)          # launches per iteration that had paths to process
     return {
         "bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(scene_file) if (scene.width, scene.height) == (800, 800) else None,
+        "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r1_pmc_traffic.json)",
+        "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_p / (steps * live_launches)),
         "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / (steps * live_launches), 1),
         "avg_launch_us": round(1e3 * ms_int / (steps * live_launches), 2),
         "nodes_per_ray": round(nodes / max(rays_s, 1), 3) if has_bvh else 0, "tris_per_ray": round(tris / max(rays_s, 1), 3) if has_bvh else 0,
@@ -189,7 +201,7 @@ def main():
 
     if rank == 0:
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
-        roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps)
+        roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)
         extra = {}
         if N == 1 and a.bvh_scene and a.bvh_scene != a.scene:
             # the HBM-fraction target is only meaningful where the kernel streams BVH data: same measurement
@@ -204,7 +216,7 @@ def main():
             bms = rb.timer_stop(); brays = rb.ray_total() - rb0
             rb.close()
             pb = measure_kernels(ptk, bs, mode, a.pipeline, a.profile_steps)
-            extra["roofline_bvh_scene"] = dict(roofline_of(bs, *pb, a.profile_steps), workload=f"scenes/{a.bvh_scene} {bs.width}x{bs.height} depth {bs.trace_depth}",
+            extra["roofline_bvh_scene"] = dict(roofline_of(bs, *pb, a.profile_steps, a.bvh_scene), workload=f"scenes/{a.bvh_scene} {bs.width}x{bs.height} depth {bs.trace_depth}",
                                                mrays_per_s=round(brays / bms / 1e3, 1))
         cpu = None
         if N == 1 and a.cpu_seconds > 0:
