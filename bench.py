@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=3, help="iterations in flight (ptk_set_iterations_in_flight)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay iterations from a hipGraph")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: samples per launch = N (weak) or 1 (strong)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--bvh-scene", default="bunny_cornell.txt", help="second roofline measurement on a BVH scene ('' = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="ptk_set_pipeline value (A/B comparisons)")
     return ap.parse_args()
@@ -152,10 +153,10 @@ def main():
         N = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=N)
+        dist.init_process_group(a.backend, rank=rank, world_size=N)
 
     mode = {"bsdf": ptk.MODE_BSDF, "direct": ptk.MODE_DIRECTLI, "mis": ptk.MODE_MIS}[a.mode]
     scene_path = os.path.join(ROOT, "scenes", a.scene)
@@ -175,11 +176,19 @@ def main():
         if N > 1:
             dist.barrier()
 
+    def reduce_radiance():
+        """the job's one collective: SUM-reduce of the full-frame float32 radiance buffer to rank 0"""
+        r.image_to(red)
+        if a.backend == "nccl":
+            dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
+        else:                                  # rehearsal backends: stage through the host
+            h = red.cpu(); dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+
     it = 0
     for _ in range(a.warmup):
         it += 1; r.iterate(it)
     if N > 1:                      # warm the communicator outside the timed region
-        r.image_to(red); dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
+        reduce_radiance()
     barrier()
     rays0 = r.ray_total()
     barrier()
@@ -189,15 +198,16 @@ def main():
         it += 1; r.iterate(it)
     dev_ms = r.timer_stop()
     if N > 1:
-        r.image_to(red); dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
+        reduce_radiance()
     barrier()
     elapsed = time.perf_counter() - t0
     rays = r.ray_total() - rays0
     counts, traced = r.live_counts()
     r.close()
     if N > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
-        q = torch.tensor([rays], dtype=torch.int64, device="cuda"); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
+        dev = "cuda" if a.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        q = torch.tensor([rays], dtype=torch.int64, device=dev); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
 
     if rank == 0:
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
@@ -228,7 +238,7 @@ def main():
             "config": {"workload": f"scenes/{a.scene} {scene.width}x{scene.height} depth {scene.trace_depth}, SampleMode {a.mode.upper()}"
                                    + (" (BASELINE configs[1])" if a.scene == "cornell.txt" and res is None and a.depth < 0 and a.mode == "bsdf" else ""),
                        "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce_last_step_rank0": [int(c) for c in counts],
-                       "sharding": "none" if N == 1 else (f"interleaved row tiles of {a.tile_rows} rows (tile %% {N} == rank), {spp} sample(s) of the owned "
+                       "sharding": "none" if N == 1 else (f"interleaved row tiles of {a.tile_rows} rows (tile % {N} == rank), {spp} sample(s) of the owned "
                                                           f"pixels per launch, one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
                        "pipeline": "staged: intersect / shade / scatter per bounce, device-resident counts, no host sync"},
