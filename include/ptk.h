@@ -180,11 +180,12 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 /* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
-/* Pipeline selection (A/B comparisons; all produce identical results):
- *   0 = staged kernels, BVH walked inside the intersect kernel, one ray per lane (default);
- *   1 = BVH walked by a separate kernel over a work list of the rays that enter the root box (measured slower: the
- *       contended list-append atomic costs more than the denser waves save);
- *   2 = like 0 with two rays per lane (measured slower: the walk is bounded by its longest dependent chain). */
+/* Pipeline selection (A/B comparisons; all produce identical results).  Only scenes with triangles differ:
+ *   0 = default: analytic primitives + BVH root-box test per ray, stable compaction of the rays that enter the root box into
+ *       a work list, BVH walk over the list (one listed ray per lane), finalize.  ~9 % faster than 1 on the bunny scene with
+ *       3 iterations in flight (denser waves in the divergent walk);
+ *   1 = the BVH is walked inside the intersect kernel for every ray, one ray per lane;
+ *   2 = like 1 with two rays per lane (measured slower). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 

@@ -126,7 +126,7 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
-    l.ws.inline_bvh = (g.pipeline != 1);
+    l.ws.inline_bvh = (g.pipeline != 0);
     l.ws.capacity = g.capacity;
     l.last_iter = 0;
     return 0;
@@ -371,7 +371,7 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 2) return PTK_E_BADARG;
     g.pipeline = which;
-    for (Lane& l : g.lanes) l.ws.inline_bvh = (which != 1);
+    for (Lane& l : g.lanes) l.ws.inline_bvh = (which != 0);
     set_rays_per_lane(which == 2 ? 2 : 1);
     return 0;
 }

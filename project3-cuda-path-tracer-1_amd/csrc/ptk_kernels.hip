@@ -95,17 +95,22 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
 // computeIntersections, pathtrace.cu:169-346
 //
 // Triangle-free scenes: k_intersect<*, false> does everything (analytic primitives only; the empty BVH root cannot hit).
-// Scenes with triangles run three kernels, because per-ray traversal cost is bimodal (bunny scene: ~80 % of the rays miss
-// the mesh's root box and cost 1 node visit, the rest ~60; with one ray per lane a wave runs for its slowest lane and lane
-// utilisation in the walk is ~15 %):
+// Scenes with triangles run four kernels by default, because per-ray traversal cost is bimodal (bunny scene: 55-70 % of the
+// rays miss the mesh's root box and cost 1 node visit, the rest ~40 with a tail beyond 200; with one ray per lane a wave
+// runs for its slowest lane and lane utilisation in the walk is ~15 %):
 //   k_intersect<*, true>  analytic primitives for every ray (uniform loop, no divergence) + the ROOT box test; rays that
-//                         enter the root box are appended to a work list (one wave-aggregated atomic per wave);
-//   k_traverse            the threaded-BVH walk, one listed ray per lane: every lane now holds a "heavy" ray.  List order is
-//                         arbitrary but rays are independent, so every per-ray result is the same for any order;
+//                         enter the root box are flagged;
+//   k_list                stable compaction of the flagged ray indices into a work list (ballot + block prefix, no atomics);
+//   k_traverse            the threaded-BVH walk, one listed ray per lane: every lane now holds a "heavy" ray (utilisation
+//                         ~30 %).  Rays are independent, so every per-ray result is the same for any schedule;
 //   k_finalize            turns (triangle, u, v, t) winners into full hit records (coalesced) and builds the per-block
 //                         aggregates the shading kernel's virtual compaction needs.
-// (A persistent-wave variant that refilled idle lanes from a global ray counter was measured and dropped: with ~400 rays
-//  per SIMD per bounce there are too few rays per wave for refill to reach a steady state; 2.5 ms vs 1.4 ms per iteration.)
+// Measured on MI355X (bunny scene, ms per iteration): inline walk 1.34 / 0.79 (1 / 3 iterations in flight), this layout
+// 1.43 / 0.72.  Alone on the GPU the walk is bounded by its longest dependent-load chain (~240 visits x ~1100 cycles) with
+// ~1 wave per SIMD left, so denser waves do not help; with other iterations' kernels filling the idle SIMDs the machine
+// becomes VALU-bound and the denser waves win.  Two dropped variants: appending to the list with one wave-aggregated atomic
+// per wave (10 k contended atomics on one word: +48 us per launch), and a persistent-wave walk that refilled idle lanes from a
+// global ray counter (too few rays per SIMD for refill to reach a steady state: 2.5 ms).
 // ------------------------------------------------------------------------------------------------------------------
 #define PTK_VALID_TRI 2          // flag value between k_traverse and k_finalize: "closest hit is a triangle, record pending"
 
@@ -113,7 +118,7 @@ template <bool STATS, bool SPLIT>
 __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
                                                           unsigned long long* ray_total, unsigned long long* stats,
-                                                          unsigned* list_count, int* __restrict__ list) {
+                                                          int* __restrict__ heavy_flag, int* __restrict__ heavy_agg) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
@@ -148,15 +153,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
         }
         valid[i] = flag;
     }
-    if (SPLIT) {                                    // append the rays that entered the root box to the traversal list
-        const unsigned long long hm = __ballot(heavy);
-        if (hm) {
-            const int lane = threadIdx.x & 63;
-            unsigned base = 0;
-            if (lane == (__ffsll((long long)hm) - 1)) base = atomicAdd(list_count, (unsigned)__popcll(hm));
-            base = __shfl(base, __ffsll((long long)hm) - 1, 64);
-            if (heavy) list[base + __popcll(hm & ((1ull << lane) - 1ull))] = i;
-        }
+    if (SPLIT) {                                    // flag the rays that entered the root box; k_list compacts them into a work list
+        if (i < n) heavy_flag[i] = heavy ? 1 : 0;
+        int total;
+        (void)block_excl_prefix(heavy ? 1 : 0, total);
+        if (threadIdx.x == 0) heavy_agg[b] = total;
     }
     if (agg) {
         int total;
@@ -260,6 +261,21 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect2(SceneView S, int n_arg
     }
 }
 
+// stable compaction of the flagged ray indices into the traversal work list (same scheme as k_scatter, 4-byte payload)
+__global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
+                                                     const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0) *list_count = 0u; return; }
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    const int flag = (i < n) ? heavy_flag[i] : 0;
+    int total;
+    const int local = block_excl_prefix(flag, total);
+    const int prior = prior_blocks(heavy_agg, b);
+    if (flag) list[prior + local] = i;
+    if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *list_count = (unsigned)(prior + total);
+}
+
 // BVH traversal of the listed rays, one per lane (pathtrace.cu:236-279).  A triangle winner is parked as (u, v, t, tri) in
 // the ray's uv_ids slot with flag PTK_VALID_TRI; k_finalize expands it (and clears the list counter for the next bounce).
 template <bool STATS>
@@ -293,10 +309,9 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
 }
 
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits,
-                                                         int* __restrict__ valid, int* __restrict__ agg, unsigned* list_count) {
+                                                         int* __restrict__ valid, int* __restrict__ agg) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
-    if (b == 0 && threadIdx.x == 0 && list_count) *list_count = 0u;    // k_traverse (previous kernel) has consumed it
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     int flag = 0;
@@ -679,11 +694,11 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
-                           unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, bool inline_bvh,
-                           hipStream_t st, void (*mark)(int, bool)) {
+                           unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
+                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool)) {
     const int g = grid_for(n);
     if (g == 0) return 0;
-    const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr;
+    const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
     mark(1, true);
     if (!split && g_rays_per_lane == 2) {
         const int g2 = (n + 2 * PTK_BLOCK - 1) / (2 * PTK_BLOCK);
@@ -698,13 +713,15 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
         mark(1, false);
         return launch_rc();
     }
-    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, queue, list);
-    else k_intersect<false, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, queue, list);
+    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg);
+    else k_intersect<false, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
+    k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue);
+    rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg, queue);
+    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg);
     mark(1, false);
     return launch_rc();
 }
@@ -717,8 +734,9 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
     const int g = grid_for(capacity);
     if (g == 0) return 0;
     const int* d_n = ws.counts + depth;
+    // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
-                                    ws.inline_bvh, st, mark);
+                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark);
     if (rc) return rc;
     mark(2, true);
     rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, st);
@@ -774,7 +792,7 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
         g_abi_list_cap = n;
     }
     return launch_intersect_stage(dev_view(*s->scene), n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
-                                  false, (hipStream_t)stream, [](int, bool) {});
+                                  nullptr, nullptr, true, (hipStream_t)stream, [](int, bool) {});
 }
 
 int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkHits hits_in,

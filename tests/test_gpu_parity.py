@@ -142,6 +142,25 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
+    """ptk_set_pipeline variants (1 = BVH walked inside the intersect kernel, 2 = the same with two rays per lane; the default 0
+    is the work-list layout exercised by every other test) produce exactly the oracle's results."""
+    for name, res, depth, mode in (("bunny_cornell.txt", (128, 128), 5, "MIS"), ("obj_test.txt", (64, 64), 4, "BSDF"), ("cornell.txt", (96, 96), 4, "BSDF")):
+        m = MODES[mode]
+        s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+        o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+        r = ptk.Renderer(s, m, pipeline=pipeline)
+        ref = np.zeros((o.P, 3), np.float32)
+        for it in (1, 2, 3):
+            r.iterate(it)
+            _, live = o.pathtrace(m, it, ref)
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, live), (name, it)
+        img = r.image(); r.close()
+        assert np.array_equal(img, ref), name
+
+
 def test_compact_edges(ptk, torch_cuda):
     """Stable compaction: empty, single, block-boundary and ragged sizes, all-dead / all-alive / random flags."""
     torch = torch_cuda
