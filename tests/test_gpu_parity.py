@@ -161,6 +161,66 @@ def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
         assert np.array_equal(img, ref), name
 
 
+def test_intersect_edge_rays(ptk, orc, torch_cuda):
+    """Hand-made rays through ptk_intersect: axis-parallel directions (zero components take the containment branch of
+    Bounds3::IntersectP, Bounds3.hpp:174-177, and divide-by-zero slabs in the box test), origins inside primitives, rays that
+    start on a surface, rays that miss everything, grazing rays along wall planes."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    for name in ("bunny_cornell.txt", "cornell.txt", "obj_test.txt", "mis_test.txt"):
+        s = ptk.Scene(os.path.join(SC, name), res=(32, 32)).upload()
+        o = orc.Scene(os.path.join(SC, name), res=(32, 32))
+        rays = []
+        axes = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (0.6, 0.8, 0), (0, 0.6, -0.8), (-0.8, 0, 0.6)]
+        for origin in ((0, 5, 3), (0, 2.5, -1), (2, 5, 2), (-2, 4, -2), (0, 9.99, 0), (0, 0.005, 0), (-2.3, 4.5, -1.2), (4.985, 5, 0), (0, 5, 50)):
+            for d in axes:
+                rays.append((origin, d))
+        for _ in range(700):                      # random origins in / around the box, axis-parallel or planar directions
+            org = rng.uniform(-6, 6, 3) * (1, 1, 1) + (0, 5, 0)
+            d = np.array(axes[rng.integers(len(axes))], np.float64)
+            rays.append((tuple(org), tuple(d)))
+        for _ in range(300):                      # fully random
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            rays.append((tuple(rng.uniform(-5, 5, 3) + (0, 5, 0)), tuple(d)))
+        n = len(rays)
+        paths = np.zeros(n, orc.PATH_DT)
+        paths["o"] = np.array([r[0] for r in rays], np.float32); paths["d"] = np.array([r[1] for r in rays], np.float32)
+        paths["color"] = 1; paths["pixelIndex"] = np.arange(n) % 1024; paths["remainingBounces"] = 4; paths["prevPdf"] = -1
+        ref_is, ref_valid = o.intersect(paths)
+        A = _to_dev(torch, orc.paths_to_soa(paths)); H = ptk.new_paths(n)
+        valid = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ptk.intersect(s, n, A, H, valid)
+        assert np.array_equal(valid.cpu().numpy(), ref_valid), name
+        got = orc.isects_from_soa(*[h.cpu().numpy() for h in H])
+        m = ref_valid.astype(bool)
+        _eq_fields(got[m], ref_is[m], what=name)
+        assert 0 < m.sum() < n or name == "cornell.txt"
+
+
+def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
+    """csrc/ptk_headless (the replay of main.cpp's call sequence through the C++ API pathtraceInit/pathtrace/pathtraceFree):
+    its raw radiance sum equals the oracle's, and TracedDepth / the x-flipped 8-bit image are produced."""
+    import subprocess
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
+    base = str(tmp_path / "out")
+    cmd = [exe, os.path.join(SC, "cornell.txt"), "--mode", "bsdf", "--iters", "3", "--res", "64", "48", "--depth", "4", "--out", base]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "TracedDepth 4" in r.stdout
+    img = np.fromfile(base + ".3samp.f32", np.float32).reshape(-1, 3)
+    o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(64, 48), depth=4)
+    ref = np.zeros((o.P, 3), np.float32)
+    for it in (1, 2, 3):
+        o.pathtrace(orc.MODE_BSDF, it, ref)
+    assert np.array_equal(img, ref)
+    raw = open(base + ".3samp.ppm", "rb").read()
+    assert raw.startswith(b"P6\n64 48\n255\n")
+    pix = np.frombuffer(raw[len(b"P6\n64 48\n255\n"):], np.uint8).reshape(48, 64, 3)
+    tm = np.zeros((o.P, 4), np.uint8); orc.L.orc_tonemap(ref.ctypes.data, o.P, 3, tm.ctypes.data)
+    want = tm[:, :3].reshape(48, 64, 3)[:, ::-1, :]            # saveImage writes pixel x at width-1-x (main.cpp:158)
+    assert np.abs(pix.astype(int) - want.astype(int)).max() <= 1
+
+
 def test_compact_edges(ptk, torch_cuda):
     """Stable compaction: empty, single, block-boundary and ragged sizes, all-dead / all-alive / random flags."""
     torch = torch_cuda
