@@ -3,7 +3,8 @@
 //   Scene(file) -> camera orbit fix-ups -> InitDataContainer -> setDevData -> loop { runCuda() } -> saveImage
 // runCuda(): at iteration 0 pathtraceFree(); pathtraceInit(scene); then iteration++ and pathtrace(pbo, 0, iteration)
 // (1-based) until `iterations`, then saveImage(): mean -> ACES -> gamma -> x-flipped 8-bit image.
-// Output: binary PPM (P6) + raw float32 radiance sum (.f32); PNG needs stb/zlib which this build does not vendor.
+// Output: 8-bit RGB PNG like image::savePNG (image.cpp:56-73; written here with zlib instead of stb_image_write),
+// binary PPM (P6) and the raw float32 radiance sum (.f32).
 //
 // usage: ptk_headless SCENE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]
 #include "pathtrace.h"
@@ -14,8 +15,41 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <zlib.h>
 
 SampleMode sampleMode = MIS;        // main.cpp:20
+
+// minimal PNG encoder: 8-bit RGB, filter 0 on every scanline, one zlib stream in one IDAT chunk
+static bool writePNG(const std::string& path, int W, int H, const unsigned char* rgb) {
+    std::vector<unsigned char> raw((size_t)H * (3 * (size_t)W + 1));
+    for (int y = 0; y < H; ++y) {
+        raw[(size_t)y * (3 * W + 1)] = 0;
+        std::memcpy(&raw[(size_t)y * (3 * W + 1) + 1], rgb + (size_t)y * 3 * W, (size_t)3 * W);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto be32 = [](unsigned v, unsigned char* o) { o[0] = v >> 24; o[1] = v >> 16; o[2] = v >> 8; o[3] = v; };
+    auto chunk = [&](const char* tag, const unsigned char* data, unsigned len) {
+        unsigned char hdr[8]; be32(len, hdr); std::memcpy(hdr + 4, tag, 4);
+        std::fwrite(hdr, 1, 8, f);
+        if (len) std::fwrite(data, 1, len, f);
+        uLong c = crc32(0L, (const Bytef*)tag, 4);
+        if (len) c = crc32(c, data, len);
+        unsigned char crc[4]; be32((unsigned)c, crc); std::fwrite(crc, 1, 4, f);
+    };
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::fwrite(sig, 1, 8, f);
+    unsigned char ihdr[13]; be32((unsigned)W, ihdr); be32((unsigned)H, ihdr + 4);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;      // 8 bit, colour type 2 (RGB)
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (unsigned)zlen);
+    chunk("IEND", nullptr, 0);
+    std::fclose(f);
+    return true;
+}
 
 static float aces(float x) {        // utilities.h:35-43
     const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
@@ -38,6 +72,8 @@ static void saveImage(const Scene& scene, int iteration, const std::string& base
                 o[k] = (unsigned char)v;
             }
         }
+    const std::string png = base + "." + std::to_string(iteration) + "samp.png";
+    if (writePNG(png, W, H, bytes.data())) std::printf("Saved %s.\n", png.c_str());
     const std::string ppm = base + "." + std::to_string(iteration) + "samp.ppm";
     if (FILE* f = std::fopen(ppm.c_str(), "wb")) {
         std::fprintf(f, "P6\n%d %d\n255\n", W, H);

@@ -219,6 +219,9 @@ def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
     tm = np.zeros((o.P, 4), np.uint8); orc.L.orc_tonemap(ref.ctypes.data, o.P, 3, tm.ctypes.data)
     want = tm[:, :3].reshape(48, 64, 3)[:, ::-1, :]            # saveImage writes pixel x at width-1-x (main.cpp:158)
     assert np.abs(pix.astype(int) - want.astype(int)).max() <= 1
+    from PIL import Image                                       # the PNG the reference's saveImage would have written
+    png = np.asarray(Image.open(base + ".3samp.png").convert("RGB"))
+    assert png.shape == (48, 64, 3) and np.array_equal(png, pix)
 
 
 def test_compact_edges(ptk, torch_cuda):
