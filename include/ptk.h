@@ -59,13 +59,15 @@ typedef struct PtkGeom {
     float transform[16], inverseTransform[16], invTranspose[16];
 } PtkGeom;
 
-/* class Material, src/material.h:524-538, constant samplers only:
- * albedo = Material::albedo (default 1, used by Light), *_s = devTexSampler::fixVal (default 0, used by the BSDFs) */
+/* class Material, src/material.h:524-538:
+ * albedo = Material::albedo (default 1, used by Light), *_s = devTexSampler::fixVal (default 0, used by the BSDFs when the
+ * matching *MapID is < 0), *MapID = index into the scene's texture list (-1 = constant sampler) */
 typedef struct PtkMaterial {
     int   type;
     float albedo[3];
     float albedo_s[3];
     float rough_s, metal_s, ior;
+    int   albedoMapID, metallicMapID, roughnessMapID, normalMapID;
 } PtkMaterial;
 
 /* class Triangle, src/Bounds3.hpp:250-258 (124 B) */
@@ -98,8 +100,13 @@ typedef struct PtkScene PtkScene;          /* host scene + its device image (cla
 int  ptk_scene_load(const char* file, int res_w, int res_h, int depth, PtkScene** out);
 void ptk_scene_free(PtkScene* s);                       /* Scene::clear + Resource::clear (src/main.cpp:140-141) */
 const char* ptk_scene_error(const PtkScene* s);         /* message of the last PTK_E_PARSE */
-/* counts[9] = geoms, materials, triangles, bvh_size (nodes per direction), lights, traceDepth, iterations, res.x, res.y */
+/* counts[11] = geoms, materials, triangles, bvh_size (nodes per direction), lights, traceDepth, iterations, res.x, res.y,
+ *              textures, envMapID (-1 = no ENV map) */
 int  ptk_scene_counts(const PtkScene* s, int* counts);
+/* Texture `id` (class image, src/image.h:8-51): size, and its float RGB texels (row 0 = bottom row, as loaded by the
+ * reference with stbi_set_flip_vertically_on_load(true)). */
+int  ptk_scene_get_texture_size(const PtkScene* s, int id, int* width, int* height);
+int  ptk_scene_get_texture(const PtkScene* s, int id, float* rgb_out);
 int  ptk_scene_get_camera(const PtkScene* s, PtkCamera* out);
 int  ptk_scene_get_geoms(const PtkScene* s, PtkGeom* out);
 int  ptk_scene_get_materials(const PtkScene* s, PtkMaterial* out);
@@ -118,9 +125,11 @@ int  ptk_scene_upload(PtkScene* s);
 int ptk_generate_rays(const PtkCamera* cam /*host*/, int iter, int trace_depth, PtkPaths paths, void* stream);
 
 /* computeIntersections, pathtrace.cu:169-346.  valid[i] = rayValid (0/1).  Misses get t = -1.
- * stats (optional, device, 2 x uint64): accumulates BVH node visits and triangle tests. */
+ * stats (optional, device, 2 x uint64): accumulates BVH node visits and triangle tests.
+ * img (optional, device, float[3*P]): with an ENV map in the scene, misses add color * env(direction) to their pixel
+ * (pathtrace.cu:303-311); pass NULL to skip that (paths.col_pdf is only read when img is given). */
 int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkHits hits, int* valid,
-                  unsigned long long* stats, void* stream);
+                  unsigned long long* stats, float* img, void* stream);
 
 /* compact_rays, pathtrace.cu:614-631: stable (order-preserving) stream compaction of both 48-byte streams by
  * `valid`.  Either stream may be omitted (NULL members).  The new count is written to *d_count_out (device). */

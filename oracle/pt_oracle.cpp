@@ -284,6 +284,30 @@ static inline void trig_sincos(float x, float* sn, float* cs) {
     else ptk_sincos(x, sn, cs);
 }
 
+// ptk atan2 spec (cephes atanf / atan2f structure, IEEE + - * / only); mode 0 uses glibc atan2f.
+//   atan(x): s = x < 0, x = |x|;  x > tan(3pi/8): y = pi/2, x = -(1/x);  x > tan(pi/8): y = pi/4, x = (x-1)/(x+1);  else y = 0
+//            z = x*x;  y += (((8.05374449538e-2 z - 1.38776856032e-1) z + 1.99777106478e-1) z - 3.33329491539e-1) z x + x;  s: y = -y
+//   atan2(y,x): x == 0: y < 0 -> -pi/2, y == 0 -> 0, else pi/2;  y == 0: x < 0 -> pi, else 0;
+//               w = 0 (x > 0), pi (x < 0, y >= 0), -pi (x < 0, y < 0);  result = w + atan(y/x)
+static inline float ptk_atan(float x) {
+    bool neg = x < 0; if (neg) x = -x;
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966192f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.f;
+    float z = x * x;
+    y += (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return neg ? -y : y;
+}
+static inline float ptk_atan2(float y, float x) {
+    const float PIF = 3.141592653589793238f, PIO2F = 1.5707963267948966192f;
+    if (x == 0) { if (y < 0) return -PIO2F; if (y == 0) return 0.f; return PIO2F; }
+    if (y == 0) return x < 0 ? PIF : 0.f;
+    float w = x > 0 ? 0.f : (y < 0 ? -PIF : PIF);
+    return w + ptk_atan(y / x);
+}
+static inline float trig_atan2(float y, float x) { return g_trig_mode == 0 ? atan2f(y, x) : ptk_atan2(y, x); }
+
 // ---------------------------------------------------------------------------------------
 // RNG  (intersections.h:12-20, pathtrace.cu:25-29, thrust minstd_rand + uniform_real<float>)
 // ---------------------------------------------------------------------------------------
@@ -331,12 +355,14 @@ struct Geom {            // 50 dwords
     int type, materialid;
     m4 transform, inverseTransform, invTranspose;
 };
-struct Material {        // 10 dwords.  albedo = Material::albedo (default 1); *_s = devTexSampler::fixVal (default 0)
+struct Material {        // 14 dwords.  albedo = Material::albedo (default 1); *_s = devTexSampler::fixVal (default 0); *MapID: texture or -1
     int type;
     float albedo[3];
     float albedo_s[3];
     float rough_s, metal_s, ior;
+    int albedoMapID, metallicMapID, roughnessMapID, normalMapID;
 };
+struct Texture { int w = 0, h = 0; std::vector<float> rgb; std::string path; };   // class image (image.h:8-51): row 0 = bottom row
 struct Triangle {        // 31 dwords = 124 B (Bounds3.hpp:250-258)
     v3 v[3], n[3];
     v2 tex[3];
@@ -376,6 +402,8 @@ struct OrcScene {
     std::vector<BvhNode> bvh;          // 6 * bvh_size
     int bvh_size = 0;
     std::vector<LightPrim> lights;
+    std::vector<Texture> textures;     // pixel data is supplied by the test harness (orc_scene_set_texture): the oracle has no image decoder
+    int envMapID = -1;
     Camera cam;
     int iterations = 0, traceDepth = 0;
     std::string imageName, sceneDir;
@@ -383,6 +411,33 @@ struct OrcScene {
     int ovr_w = -1, ovr_h = -1, ovr_depth = -1;
     std::string error;
 };
+
+// ---------------------------------------------------------------------------------------
+// textures (image.h:53-110)
+// ---------------------------------------------------------------------------------------
+static inline v3 texel(const Texture& t, int x, int y) {
+    x = x < 0 ? 0 : (x >= t.w ? t.w - 1 : x);              // unchecked in the reference; clamped (only differs where that is UB)
+    y = y < 0 ? 0 : (y >= t.h ? t.h - 1 : y);
+    const float* p = &t.rgb[3 * ((size_t)y * t.w + x)];
+    return v3(p[0], p[1], p[2]);
+}
+static v3 linearSample(const Texture& t, v2 uv) {           // devTexObj::linearSample, image.h:73-85
+    float u = uv.x, v = uv.y;
+    float x = u * (t.w - 1), y = v * (t.h - 1);
+    int lx = x, ux = x + 1 >= t.w ? lx : lx + 1;
+    int ly = y, uy = y + 1 >= t.h ? ly : ly + 1;
+    float fx = x - floorf(x), fy = y - floorf(y);
+    v3 p1 = mixv(texel(t, lx, ly), texel(t, ux, ly), fx);
+    v3 p2 = mixv(texel(t, lx, uy), texel(t, ux, uy), fx);
+    return mixv(p1, p2, fy);
+}
+static inline v2 sphere2Plane(v3 dir) {                     // utilities.h:209-214 ("* InvPI" == "* 1.f/PI")
+    v2 r;
+    float a = trig_atan2(dir.z, dir.x) * 1.f / PI_F * .5f + 1.f;
+    r.x = a - floorf(a);
+    r.y = gmax(trig_atan2(dir.y, sqrtf(dir.x * dir.x + dir.z * dir.z)) * 1.f / PI_F + 0.5f, 0.f);
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------
 // primitives
@@ -526,8 +581,22 @@ static int intersect_one(const OrcScene& S, const PathSegment& ps, Isect& out) {
     out.materialId = S.geoms[hit_geom].materialid;
     out.uv.x = gclamp(uv.x, 0.f, 1.f); out.uv.y = gclamp(uv.y, 0.f, 1.f);
     out.geomID = hit_geom; out.triangleID = triId;
-    // normalSampler is force-reset to (0.5,0.5,1) (scene.cpp:311): localNorm = (0,0,1) -> plain normal (pathtrace.cu:323-340)
-    out.n = normalize(N);
+    // pathtrace.cu:323-340.  The constant normal sampler is (0.5,0.5,1) (scene.cpp:311): localNorm = (0,0,1) -> plain normal.
+    v3 normal = normalize(N);
+    out.n = normal;
+    const Material& hm = S.materials[out.materialId];
+    if (hm.normalMapID >= 0 && hm.normalMapID < (int)S.textures.size()) {
+        v3 mapped = linearSample(S.textures[hm.normalMapID], uv);               // unclamped texCoords, like the reference
+        v3 localNorm = normalize(v3(mapped.x * 1.f - 0.5f, mapped.y * 1.f - 0.5f, mapped.z * 1.f - 0.5f));
+        v3 T = triId >= 0 ? S.triangles[triId].tangent : v3();
+        if (dot(T, T) > 1e-3f && (double)fabsf(localNorm.z - 1.f) > 1e-5) {
+            v3 B = normalize(cross(normal, T));
+            T = normalize(cross(B, normal));
+            out.n = normalize(v3(T.x * localNorm.x + B.x * localNorm.y + normal.x * localNorm.z,
+                                 T.y * localNorm.x + B.y * localNorm.y + normal.y * localNorm.z,
+                                 T.z * localNorm.x + B.z * localNorm.y + normal.z * localNorm.z));
+        }
+    }
     return 1;
 }
 
@@ -644,9 +713,21 @@ static inline float powerHeuristic(float f, float g) { return (f * f) / (f * f +
 
 struct ScatterRec { v3 bsdf; float pdf = 0; v3 dir; };
 
-static inline float mat_rough(const Material& m) { return gclamp(m.rough_s, (float)ROUGHNESS_MIN, ROUGHNESS_MAX); }
-static inline float mat_metal(const Material& m) { return gclamp(m.metal_s, 0.f, 1.f); }
-static inline v3 mat_albedo_s(const Material& m) { return v3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]); }
+// the devTexSampler::linearSample(uv) calls of material.h: a bound texture, else the constant
+static const OrcScene* g_tex_scene = nullptr;      // scene whose textures the samplers refer to (set by the entry points)
+static v2 g_uv;                                    // intersection.texCoords of the hit being shaded
+static inline bool has_tex(int id) { return g_tex_scene && id >= 0 && id < (int)g_tex_scene->textures.size(); }
+static inline float mat_rough(const Material& m) {
+    float r = has_tex(m.roughnessMapID) ? linearSample(g_tex_scene->textures[m.roughnessMapID], g_uv).x : m.rough_s;
+    return gclamp(r, (float)ROUGHNESS_MIN, ROUGHNESS_MAX);
+}
+static inline float mat_metal(const Material& m) {
+    float r = has_tex(m.metallicMapID) ? linearSample(g_tex_scene->textures[m.metallicMapID], g_uv).x : m.metal_s;
+    return gclamp(r, 0.f, 1.f);
+}
+static inline v3 mat_albedo_s(const Material& m) {
+    return has_tex(m.albedoMapID) ? linearSample(g_tex_scene->textures[m.albedoMapID], g_uv) : v3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+}
 
 // material.h:246-261
 static v3 microfacetBSDF(v3 n, v3 wo, v3 wi, v3 albedo, float rough) {
@@ -693,7 +774,7 @@ static float metallicPDF(v3 n, v3 wo, v3 wi, float rough, float metal) {
 
 // material.h:450-481 Material::scatterSample.  wo = incident ray direction (points INTO the surface).
 static void scatterSample(const Material& m, const Isect& is, v3 wo, ScatterRec& srec, Rng& rng) {
-    v3 n = is.n;
+    v3 n = is.n; g_uv = is.uv;
     switch (m.type) {
     case MAT_LAMBERTIAN: {                                             // material.h:56-62
         srec.bsdf = mat_albedo_s(m) / PI_F;
@@ -742,7 +823,7 @@ static void scatterSample(const Material& m, const Isect& is, v3 wo, ScatterRec&
 }
 // material.h:483-501
 static v3 matBSDF(const Material& m, const Isect& is, v3 wo, v3 wi) {
-    v3 n = is.n;
+    v3 n = is.n; g_uv = is.uv;
     switch (m.type) {
     case MAT_LAMBERTIAN: return mat_albedo_s(m) / PI_F;
     case MAT_MICROFACET: return microfacetBSDF(n, -1.f * wo, wi, mat_albedo_s(m), mat_rough(m));
@@ -752,7 +833,7 @@ static v3 matBSDF(const Material& m, const Isect& is, v3 wo, v3 wi) {
 }
 // material.h:503-521
 static float matPDF(const Material& m, const Isect& is, v3 wo, v3 wi) {
-    v3 n = is.n;
+    v3 n = is.n; g_uv = is.uv;
     switch (m.type) {
     case MAT_LAMBERTIAN: return dot(wi, n) / PI_F;
     case MAT_MICROFACET: return microfacetPDF(n, -1.f * wo, wi, mat_rough(m));
@@ -972,13 +1053,6 @@ static bool safeGetline(std::istream& is, std::string& t) {   // utilities.cpp:8
     }
 }
 static bool file_exists(const std::string& p) { std::ifstream f(p.c_str()); return f.good(); }
-// The reference first tries to open the first value token of ALBEDO/METALLIC/ROUGHNESS as an image (scene.cpp:276,284,292)
-// and falls back to the numeric path when that fails.  Texture maps are out of scope this round:
-// a token that is not a plain number is reported as unsupported instead of being loaded.
-static bool looks_like_texture(const std::string& t) {
-    char* e = nullptr; strtod(t.c_str(), &e);
-    return e == t.c_str() || *e != 0;
-}
 static std::string resolve_path(const OrcScene& S, std::string p) {
     std::replace(p.begin(), p.end(), '\\', '/');
     if (file_exists(p)) return p;                       // reference: relative to the process CWD
@@ -1039,11 +1113,24 @@ static bool loadObj(OrcScene& S, const std::string& file, int geomIdx, std::vect
     return true;
 }
 
+// Scene::loadTexture, scene.cpp:318-337: returns the texture id when the token names an existing non-empty file (pixel
+// data comes later from the harness), -1 otherwise (the caller then falls back to numbers, scene.cpp:276-297).
+static int loadTextureRef(OrcScene& S, const std::string& token) {
+    std::string path = resolve_path(S, token);
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f.good() || f.peek() == EOF) return -1;
+    for (size_t i = 0; i < S.textures.size(); ++i) if (S.textures[i].path == path) return (int)i;
+    Texture t; t.path = path;
+    S.textures.push_back(t);
+    return (int)S.textures.size() - 1;
+}
+
 static int loadMaterial(OrcScene& S, std::istream& in, const std::string& name) {   // scene.cpp:243-316
     if (S.materialNameMap.count(name)) return -1;
     Material m; memset(&m, 0, sizeof m);
     m.type = 0;                                 // uninitialised in the reference; 0 (Lambertian) in practice
     m.albedo[0] = m.albedo[1] = m.albedo[2] = 1.f; m.ior = 1.5f;
+    m.albedoMapID = m.metallicMapID = m.roughnessMapID = m.normalMapID = -1;
     for (int i = 0; i < 6; i++) {
         std::string line; safeGetline(in, line);
         std::vector<std::string> tk = tokenize(line);
@@ -1052,16 +1139,16 @@ static int loadMaterial(OrcScene& S, std::istream& in, const std::string& name) 
             static const char* names[5] = {"Lambertian", "MetallicWorkflow", "Dielectric", "Microfacet", "Light"};
             for (int k = 0; k < 5; ++k) if (tk.size() > 1 && tk[1] == names[k]) m.type = k;
         } else if (tk[0] == "ALBEDO") {
-            if (looks_like_texture(tk[1])) { S.error = "texture maps unsupported: " + tk[1]; return -2; }
-            for (int k = 0; k < 3; ++k) { m.albedo[k] = (float)atof(tk[1 + k].c_str()); m.albedo_s[k] = m.albedo[k]; }
+            m.albedoMapID = loadTextureRef(S, tk[1]);
+            if (m.albedoMapID < 0) for (int k = 0; k < 3; ++k) { m.albedo[k] = (float)atof(tk[1 + k].c_str()); m.albedo_s[k] = m.albedo[k]; }
         } else if (tk[0] == "METALLIC") {
-            if (looks_like_texture(tk[1])) { S.error = "texture maps unsupported: " + tk[1]; return -2; }
-            m.metal_s = (float)atof(tk[1].c_str());
+            m.metallicMapID = loadTextureRef(S, tk[1]);
+            if (m.metallicMapID < 0) m.metal_s = (float)atof(tk[1].c_str());
         } else if (tk[0] == "ROUGHNESS") {
-            if (looks_like_texture(tk[1])) { S.error = "texture maps unsupported: " + tk[1]; return -2; }
-            double r = atof(tk[1].c_str()); m.rough_s = (float)(r > ROUGHNESS_MIN ? r : ROUGHNESS_MIN);   // glm::max(double,double)
+            m.roughnessMapID = loadTextureRef(S, tk[1]);
+            if (m.roughnessMapID < 0) { double r = atof(tk[1].c_str()); m.rough_s = (float)(r > ROUGHNESS_MIN ? r : ROUGHNESS_MIN); }   // glm::max(double,double)
         } else if (tk[0] == "NORMAL") {
-            S.error = "normal maps unsupported"; return -2;
+            m.normalMapID = loadTextureRef(S, tk[1]);
         } else if (tk[0] == "IOR") {
             m.ior = (float)atof(tk[1].c_str());
         }
@@ -1324,7 +1411,7 @@ OrcScene* orc_scene_load(const char* file, int res_w, int res_h, int depth) {
         if (tk[0] == "MATERIAL") rc = loadMaterial(*S, in, tk[1]);
         else if (tk[0] == "OBJECT") rc = loadGeom(*S, in, tk[1]);
         else if (tk[0] == "CAMERA") rc = loadCamera(*S, in);
-        else if (tk[0] == "ENV") { S->error = "ENV maps unsupported"; rc = -2; }
+        else if (tk[0] == "ENV" && tk.size() > 1) S->envMapID = loadTextureRef(*S, tk[1]);
         if (rc == -2) return S;
     }
     camera_fixups(*S);
@@ -1335,10 +1422,17 @@ void orc_scene_free(OrcScene* S) { delete S; }
 const char* orc_scene_error(OrcScene* S) { return S->error.c_str(); }
 
 // counts: [0]=geoms [1]=materials [2]=triangles [3]=bvh_size [4]=lights [5]=traceDepth [6]=iterations [7]=res.x [8]=res.y
+//         [9]=textures [10]=envMapID
 void orc_scene_counts(OrcScene* S, int* out) {
+    out[9] = (int)S->textures.size(); out[10] = S->envMapID;
     out[0] = (int)S->geoms.size(); out[1] = (int)S->materials.size(); out[2] = (int)S->triangles.size();
     out[3] = S->bvh_size; out[4] = (int)S->lights.size(); out[5] = S->traceDepth; out[6] = S->iterations;
     out[7] = S->cam.res[0]; out[8] = S->cam.res[1];
+}
+const char* orc_scene_texture_path(OrcScene* S, int i) { return (i >= 0 && i < (int)S->textures.size()) ? S->textures[i].path.c_str() : ""; }
+// float RGB texels, row 0 = bottom row (what stbi_loadf(..., 3) returns after stbi_set_flip_vertically_on_load(true))
+void orc_scene_set_texture(OrcScene* S, int i, int w, int h, const float* rgb) {
+    Texture& t = S->textures[i]; t.w = w; t.h = h; t.rgb.assign(rgb, rgb + 3 * (size_t)w * h);
 }
 void orc_scene_get_geoms(OrcScene* S, void* out) { memcpy(out, S->geoms.data(), S->geoms.size() * sizeof(Geom)); }
 void orc_scene_get_materials(OrcScene* S, void* out) { memcpy(out, S->materials.data(), S->materials.size() * sizeof(Material)); }
@@ -1358,6 +1452,7 @@ uint32_t orc_seed_hash(int iter, int index, int depth) { return seed_hash(iter, 
 void orc_rng_uniforms(int iter, int index, int depth, int n, float* out) { Rng r = make_rng(iter, index, depth); for (int i = 0; i < n; ++i) out[i] = sample1D(r); }
 void orc_rng_uniforms_seed(uint32_t seed, int n, float* out) { Rng r; r.x = seed % 2147483647u; if (r.x == 0) r.x = 1; for (int i = 0; i < n; ++i) out[i] = sample1D(r); }
 void orc_sincos(float x, float* s, float* c) { trig_sincos(x, s, c); }
+void orc_ptk_atan2_array(const float* y, const float* x, int n, float* out) { for (int i = 0; i < n; ++i) out[i] = ptk_atan2(y[i], x[i]); }
 void orc_ptk_sincos_array(const float* x, int n, float* s, float* c) { for (int i = 0; i < n; ++i) ptk_sincos(x[i], s + i, c + i); }
 
 // geom given as 50 dwords; ray o[3], d[3]; out: t, P[3], N[3]
@@ -1414,13 +1509,24 @@ void orc_generate_rays(OrcScene* S, int iter, void* paths) {
     PathSegment* p = (PathSegment*)paths; const Camera& cam = S->cam;
     for (int y = 0; y < cam.res[1]; ++y) for (int x = 0; x < cam.res[0]; ++x) generate_ray(cam, iter, S->traceDepth, x, y, p[x + y * cam.res[0]]);
 }
-void orc_intersect(OrcScene* S, int n, const void* paths, void* isects, int* valid) {
+// img (optional): with an ENV map, a miss adds color * env(sphere2Plane(direction)) to its pixel (pathtrace.cu:303-311)
+void orc_intersect_env(OrcScene* S, int n, const void* paths, void* isects, int* valid, float* img) {
     const PathSegment* p = (const PathSegment*)paths; Isect* is = (Isect*)isects;
-    for (int i = 0; i < n; ++i) valid[i] = intersect_one(*S, p[i], is[i]);
+    g_tex_scene = S;
+    const bool env = img && S->envMapID >= 0 && S->envMapID < (int)S->textures.size();
+    for (int i = 0; i < n; ++i) {
+        valid[i] = intersect_one(*S, p[i], is[i]);
+        if (!valid[i] && env) {
+            v3 c = processNAN(p[i].color * linearSample(S->textures[S->envMapID], sphere2Plane(p[i].d)));
+            float* px = radiance_px(img, p[i].pixelIndex); px[0] += c.x; px[1] += c.y; px[2] += c.z;
+        }
+    }
 }
+void orc_intersect(OrcScene* S, int n, const void* paths, void* isects, int* valid) { orc_intersect_env(S, n, paths, isects, valid, nullptr); }
 // shade n compacted paths in place; idx = compacted slot index (the RNG key).  img: float[3*P] accumulated.
 void orc_shade(OrcScene* S, int mode, int iter, int depth, int n, const void* isects, void* paths, int* valid, float* img) {
     PathSegment* p = (PathSegment*)paths; const Isect* is = (const Isect*)isects;
+    g_tex_scene = S;
     for (int i = 0; i < n; ++i) {
         if (mode == MODE_BSDF) valid[i] = shade_bsdf(*S, iter, i, depth, is[i], p[i], img);
         else if (mode == MODE_MIS) valid[i] = shade_mis(*S, iter, i, depth, is[i], p[i], img);
@@ -1467,7 +1573,7 @@ long long orc_pathtrace_batch(OrcScene* S, int mode, int step, int spp, int n_pa
         if (depth <= S->traceDepth) live[depth] = n;
         rays += n;
         auto a = clk::now();
-        orc_intersect(S, n, paths.data(), isects.data(), valid.data());
+        orc_intersect_env(S, n, paths.data(), isects.data(), valid.data(), img);
         auto b = clk::now();
         n = orc_compact(n, valid.data(), paths.data(), isects.data());
         auto c = clk::now();

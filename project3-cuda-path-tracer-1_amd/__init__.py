@@ -32,7 +32,7 @@ E_BADARG, E_NOSCENE, E_PARSE, E_NODEVICE = 1001, 1002, 1003, 1004
 ABI_SYMBOLS = [
     "ptk_scene_load", "ptk_scene_free", "ptk_scene_error", "ptk_scene_counts", "ptk_scene_get_camera",
     "ptk_scene_get_geoms", "ptk_scene_get_materials", "ptk_scene_get_triangles", "ptk_scene_get_bvh",
-    "ptk_scene_get_lights", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
+    "ptk_scene_get_lights", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
     "ptk_shade", "ptk_tonemap", "ptk_pathtrace_init", "ptk_pathtrace_free", "ptk_pathtrace",
     "ptk_set_sample_mode", "ptk_get_sample_mode", "ptk_get_image", "ptk_get_image_device",
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
@@ -73,7 +73,8 @@ class PtkHits(C.Structure):
 
 # numpy views of the interchange PODs (include/ptk.h), dword-for-dword
 GEOM_DT = np.dtype([("type", "<i4"), ("materialid", "<i4"), ("transform", "<f4", 16), ("inverseTransform", "<f4", 16), ("invTranspose", "<f4", 16)])
-MATERIAL_DT = np.dtype([("type", "<i4"), ("albedo", "<f4", 3), ("albedo_s", "<f4", 3), ("rough_s", "<f4"), ("metal_s", "<f4"), ("ior", "<f4")])
+MATERIAL_DT = np.dtype([("type", "<i4"), ("albedo", "<f4", 3), ("albedo_s", "<f4", 3), ("rough_s", "<f4"), ("metal_s", "<f4"), ("ior", "<f4"),
+                        ("albedoMapID", "<i4"), ("metallicMapID", "<i4"), ("roughnessMapID", "<i4"), ("normalMapID", "<i4")])
 TRIANGLE_DT = np.dtype([("v", "<f4", 9), ("n", "<f4", 9), ("tex", "<f4", 6), ("tangent", "<f4", 3), ("bitangent", "<f4", 3), ("geomIdx", "<i4")])
 BVHNODE_DT = np.dtype([("pMin", "<f4", 3), ("pMax", "<f4", 3), ("start", "<i4"), ("end", "<i4"), ("miss", "<i4"), ("hit", "<i4")])
 LIGHT_DT = np.dtype([("geomID", "<i4"), ("triangleID", "<i4"), ("type", "<i4")])
@@ -108,8 +109,10 @@ def _load() -> C.CDLL:
     for name in ("counts", "get_camera", "get_geoms", "get_materials", "get_triangles", "get_bvh", "get_lights"):
         getattr(lib, "ptk_scene_" + name).argtypes = [vp, vp]
     lib.ptk_scene_upload.argtypes = [vp]
+    lib.ptk_scene_get_texture_size.argtypes = [vp, ci, vp, vp]
+    lib.ptk_scene_get_texture.argtypes = [vp, ci, vp]
     lib.ptk_generate_rays.argtypes = [C.POINTER(PtkCamera), ci, ci, PtkPaths, vp]
-    lib.ptk_intersect.argtypes = [vp, ci, vp, PtkPaths, PtkHits, vp, vp, vp]
+    lib.ptk_intersect.argtypes = [vp, ci, vp, PtkPaths, PtkHits, vp, vp, vp, vp]
     lib.ptk_compact.argtypes = [ci, vp, vp, PtkPaths, PtkHits, PtkPaths, PtkHits, vp, vp]
     lib.ptk_shade.argtypes = [vp, ci, ci, ci, ci, vp, PtkHits, PtkPaths, vp, vp, vp]
     lib.ptk_tonemap.argtypes = [vp, ci, ci, ci, vp, vp]
@@ -156,10 +159,10 @@ class Scene:
             lib.ptk_scene_free(h)
             self.handle = None
             raise PtkError(f"ptk_scene_load({path}): {msg}", rc)
-        c = np.zeros(9, np.int32)
+        c = np.zeros(11, np.int32)
         _chk(lib.ptk_scene_counts(h, c.ctypes.data), "ptk_scene_counts")
         (self.n_geoms, self.n_materials, self.n_triangles, self.bvh_size, self.n_lights,
-         self.trace_depth, self.iterations, self.width, self.height) = (int(x) for x in c)
+         self.trace_depth, self.iterations, self.width, self.height, self.n_textures, self.env_map_id) = (int(x) for x in c)
         self.uploaded = False
 
     def _table(self, getter, dtype, n):
@@ -174,6 +177,14 @@ class Scene:
     def triangles(self): return self._table(lib.ptk_scene_get_triangles, TRIANGLE_DT, self.n_triangles)
     def bvh(self): return self._table(lib.ptk_scene_get_bvh, BVHNODE_DT, 6 * self.bvh_size)
     def lights(self): return self._table(lib.ptk_scene_get_lights, LIGHT_DT, self.n_lights)
+
+    def texture(self, i: int) -> np.ndarray:
+        """float32 [h, w, 3], row 0 = bottom row (as the reference loads it)"""
+        w, h = C.c_int(0), C.c_int(0)
+        _chk(lib.ptk_scene_get_texture_size(self.handle, i, C.byref(w), C.byref(h)), "ptk_scene_get_texture_size")
+        out = np.zeros((h.value, w.value, 3), np.float32)
+        _chk(lib.ptk_scene_get_texture(self.handle, i, out.ctypes.data), "ptk_scene_get_texture")
+        return out
 
     def camera_struct(self) -> PtkCamera:
         cam = PtkCamera()
@@ -237,8 +248,8 @@ def generate_rays(scene: Scene, it: int, paths, trace_depth=None):
                                paths_struct(paths), _stream()), "ptk_generate_rays")
 
 
-def intersect(scene: Scene, n: int, paths, hits, valid, d_n=None, stats=None):
-    _chk(lib.ptk_intersect(scene.handle, n, _ptr(d_n), paths_struct(paths), hits_struct(hits), _ptr(valid), _ptr(stats), _stream()), "ptk_intersect")
+def intersect(scene: Scene, n: int, paths, hits, valid, d_n=None, stats=None, img=None):
+    _chk(lib.ptk_intersect(scene.handle, n, _ptr(d_n), paths_struct(paths), hits_struct(hits), _ptr(valid), _ptr(stats), _ptr(img), _stream()), "ptk_intersect")
 
 
 def compact(n: int, valid, paths_in, hits_in, paths_out, hits_out, d_count_out, d_n=None):

@@ -10,6 +10,7 @@
 //   DevTriV[T]       36 B each : vertex positions (attribute interpolation of the final hit, light sampling)
 //   DevTriA[T]       64 B each : vertex normals, texcoords, geomIdx (touched once per ray, for the final hit)
 #include "ptk_internal.h"
+#include "image.h"
 #include <cstring>
 
 using namespace ptk;
@@ -58,6 +59,11 @@ int DevScene::initiate(Scene& scene) {
         m[i].rough = clampG(s.roughnessSampler, static_cast<float>(1e-3), 1.f);     // material.h:274, 486
         m[i].metal = clampG(s.metallicSampler, 0.f, 1.f);                           // material.h:325, 487
         m[i].ior = s.ior;
+        const int T = (int)scene.textures.size();                                   // scene.cpp:597-618: bind maps that exist
+        m[i].albedo_tex = (s.albedoMapID >= 0 && s.albedoMapID < T) ? s.albedoMapID : -1;
+        m[i].rough_tex = (s.roughnessMapID >= 0 && s.roughnessMapID < T) ? s.roughnessMapID : -1;
+        m[i].metal_tex = (s.metallicMapID >= 0 && s.metallicMapID < T) ? s.metallicMapID : -1;
+        m[i].normal_tex = (s.normalMapID >= 0 && s.normalMapID < T) ? s.normalMapID : -1;
     }
     const int B = scene.bvhSize;
     std::vector<DevNode> nodes((size_t)6 * B);
@@ -81,10 +87,18 @@ int DevScene::initiate(Scene& scene) {
         te[i] = DevTriE{{v[0].x, v[0].y, v[0].z}, {v[1].x - v[0].x, v[1].y - v[0].y, v[1].z - v[0].z},
                         {v[2].x - v[0].x, v[2].y - v[0].y, v[2].z - v[0].z}, {0.f, 0.f, 0.f}};
         ta[i] = DevTriA{{n[0].x, n[0].y, n[0].z}, {n[1].x, n[1].y, n[1].z}, {n[2].x, n[2].y, n[2].z},
-                        {t.tex[0].x, t.tex[0].y}, {t.tex[1].x, t.tex[1].y}, {t.tex[2].x, t.tex[2].y}, t.geomIdx};
+                        {t.tex[0].x, t.tex[0].y}, {t.tex[1].x, t.tex[1].y}, {t.tex[2].x, t.tex[2].y}, t.geomIdx,
+                        {t.tangent.x, t.tangent.y, t.tangent.z}};
     }
     std::vector<DevLight> li;
     for (const lightPrim& l : scene.lights) li.push_back(DevLight{l.geomID, l.triangleID, (int)l.type});
+    std::vector<DevTex> tx;                                  // devTexObj table + one packed texel array (scene.cpp:575-595)
+    std::vector<float> texels;
+    for (const image* im : scene.textures) {
+        tx.push_back(DevTex{im->width, im->height, (unsigned)(texels.size() / 3), 0});
+        const float* src = reinterpret_cast<const float*>(im->data());
+        texels.insert(texels.end(), src, src + 3 * (size_t)im->width * im->height);
+    }
 
     int rc;
     if ((rc = upload(&dev_geoms, g))) return rc;
@@ -94,13 +108,16 @@ int DevScene::initiate(Scene& scene) {
     if ((rc = upload(&dev_triv, tv))) return rc;
     if ((rc = upload(&dev_tria, ta))) return rc;
     if ((rc = upload(&dev_lights, li))) return rc;
+    if ((rc = upload(&dev_textures, tx))) return rc;
+    if ((rc = upload(&dev_texture_data, texels))) return rc;
+    tex_num = (int)tx.size(); envMapID = scene.envMapID;
     tri_num = (int)tv.size(); bvh_size = B;
     uploaded = true;
     return 0;
 }
 
 void DevScene::destroy() {
-    void** ptrs[] = {&dev_geoms, &dev_materials, &dev_nodes, &dev_trie, &dev_triv, &dev_tria, &dev_lights};
+    void** ptrs[] = {&dev_geoms, &dev_materials, &dev_nodes, &dev_trie, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     uploaded = false;
 }
@@ -133,6 +150,7 @@ int ptk_scene_counts(const PtkScene* s, int* c) {
     c[0] = (int)S.geoms.size(); c[1] = (int)S.materials.size(); c[2] = (int)S.triangles.size(); c[3] = S.bvhSize;
     c[4] = (int)S.lights.size(); c[5] = S.state.traceDepth; c[6] = (int)S.state.iterations;
     c[7] = S.state.camera.resolution.x; c[8] = S.state.camera.resolution.y;
+    c[9] = (int)S.textures.size(); c[10] = S.envMapID;
     return 0;
 }
 
@@ -167,7 +185,20 @@ int ptk_scene_get_materials(const PtkScene* s, PtkMaterial* o) {
         o[i].albedo[0] = m.albedo.x; o[i].albedo[1] = m.albedo.y; o[i].albedo[2] = m.albedo.z;
         o[i].albedo_s[0] = m.albedoSampler.x; o[i].albedo_s[1] = m.albedoSampler.y; o[i].albedo_s[2] = m.albedoSampler.z;
         o[i].rough_s = m.roughnessSampler; o[i].metal_s = m.metallicSampler; o[i].ior = m.ior;
+        o[i].albedoMapID = m.albedoMapID; o[i].metallicMapID = m.metallicMapID; o[i].roughnessMapID = m.roughnessMapID; o[i].normalMapID = m.normalMapID;
     }
+    return 0;
+}
+
+int ptk_scene_get_texture_size(const PtkScene* s, int id, int* width, int* height) {
+    if (!s || !s->scene || !width || !height || id < 0 || id >= (int)s->scene->textures.size()) return PTK_E_BADARG;
+    *width = s->scene->textures[id]->width; *height = s->scene->textures[id]->height;
+    return 0;
+}
+int ptk_scene_get_texture(const PtkScene* s, int id, float* rgb_out) {
+    if (!s || !s->scene || !rgb_out || id < 0 || id >= (int)s->scene->textures.size()) return PTK_E_BADARG;
+    const image* im = s->scene->textures[id];
+    std::memcpy(rgb_out, im->data(), im->byteSize());
     return 0;
 }
 

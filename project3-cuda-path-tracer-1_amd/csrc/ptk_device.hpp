@@ -108,12 +108,14 @@ struct DevGeom {
     float invT[9];      // upper 3x3 of invTranspose, row-major
     int diag;           // 1: the 3x3 parts of inv, fwd and invT are diagonal (all off-diagonal entries are +-0)
 };
-struct DevMaterial {    // 12 dwords
+struct DevMaterial {    // 16 dwords
     int type;
     float albedo[3], albedo_s[3];
-    float rough, metal, ior;     // rough/metal already clamped like Material::BSDF does (material.h:486-487)
+    float rough, metal, ior;     // constant-sampler rough/metal already clamped like Material::BSDF does (material.h:486-487)
+    int albedo_tex, rough_tex, metal_tex, normal_tex;      // texture index per sampler, -1 = the constant above
     float pad[2];
 };
+struct DevTex { int w, h; unsigned offset; int pad; };    // devTexObj (image.h:53-66): texels at texels[3 * (offset + y*w + x)]
 // One node of a direction-ordered threaded BVH, 32 B = two 16-B loads.  a/b encode the reference's (start,end,hit,miss):
 //   a >=  0 : inner node, a = hit link (first child in this direction's order), b = miss link
 //   a == -1 : empty leaf (start == end; only the root of a triangle-free scene), b = next (hit == miss for leaves)
@@ -124,7 +126,7 @@ struct DevNode {
 };
 struct DevTriE { float v0[3], e1[3], e2[3], pad[3]; };                          // 48 B: v0 and the two edges (e = v - v0 as in Bounds3.hpp:300-301)
 struct DevTriV { float v0[3], v1[3], v2[3]; };                                  // 36 B, positions (attribute interpolation, light sampling)
-struct DevTriA { float n0[3], n1[3], n2[3]; float t0[2], t1[2], t2[2]; int geomIdx; };  // 64 B, shading attributes
+struct DevTriA { float n0[3], n1[3], n2[3]; float t0[2], t1[2], t2[2]; int geomIdx; float tangent[3]; };  // 76 B, shading attributes
 struct DevLight { int geomID, triangleID, type; };
 
 struct SceneView {
@@ -134,6 +136,7 @@ struct SceneView {
     const DevTriE* trie;         // traversal form of the triangles
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;
+    const DevTex* tex;           const float* texels;   int env_tex;     // env_tex = envMapID (-1: none)
 };
 
 // Wave-uniform load of one primitive record into SGPRs.  The scene tables are immutable while a kernel runs, but the
@@ -305,6 +308,56 @@ struct Hit {
     float t; f3 n; f3 p; f2 uv; int mat, geom, tri;
 };
 
+// ---- textures (image.h:53-110) and the environment map (utilities.h:209-214, pathtrace.cu:303-311) -------------------
+PTK_DI f3 texel(const SceneView& S, const DevTex& t, int x, int y) {
+    x = x < 0 ? 0 : (x >= t.w ? t.w - 1 : x);                 // the reference indexes unchecked; clamp instead of reading out of bounds
+    y = y < 0 ? 0 : (y >= t.h ? t.h - 1 : y);
+    const float* p = S.texels + 3 * ((size_t)t.offset + (size_t)y * t.w + x);
+    return mk3(p[0], p[1], p[2]);
+}
+// devTexObj::linearSample, image.h:73-85
+PTK_DI f3 tex_sample(const SceneView& S, int id, f2 uv) {
+    const DevTex t = S.tex[id];
+    const float x = uv.x * (t.w - 1), y = uv.y * (t.h - 1);
+    const int lx = (int)x, ux = (x + 1 >= t.w) ? lx : lx + 1;
+    const int ly = (int)y, uy = (y + 1 >= t.h) ? ly : ly + 1;
+    const float fx = x - floorf(x), fy = y - floorf(y);        // glm::fract
+    const f3 p1 = mixv(texel(S, t, lx, ly), texel(S, t, ux, ly), fx);
+    const f3 p2 = mixv(texel(S, t, lx, uy), texel(S, t, ux, uy), fx);
+    return mixv(p1, p2, fy);
+}
+// ptk atan2 specification (shared text with oracle/pt_oracle.cpp; cephes atanf/atan2f structure, IEEE + - * / only):
+//   atan(x): s = x < 0, x = |x|;  x > tan(3pi/8): y = pi/2, x = -(1/x);  x > tan(pi/8): y = pi/4, x = (x-1)/(x+1);  else y = 0
+//            z = x*x;  y += (((8.05374449538e-2 z - 1.38776856032e-1) z + 1.99777106478e-1) z - 3.33329491539e-1) z x + x;  s: y = -y
+//   atan2(y,x): x == 0: y < 0 -> -pi/2, y == 0 -> 0, else pi/2;  y == 0: x < 0 -> pi, else 0;
+//               w = 0 (x > 0), pi (x < 0, y >= 0), -pi (x < 0, y < 0);  result = w + atan(y/x)
+PTK_DI float atan_ptk(float x) {
+    const bool neg = x < 0; x = fabsf(x);
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966192f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.f;
+    const float z = x * x;
+    y += (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return neg ? -y : y;
+}
+PTK_DI float atan2_ptk(float y, float x) {
+    const float PIF = 3.141592653589793238f, PIO2F = 1.5707963267948966192f;
+    if (x == 0) { if (y < 0) return -PIO2F; if (y == 0) return 0.f; return PIO2F; }
+    if (y == 0) return x < 0 ? PIF : 0.f;
+    const float w = x > 0 ? 0.f : (y < 0 ? -PIF : PIF);
+    return w + atan_ptk(y / x);
+}
+// math::sphere2Plane, utilities.h:209-214 ("* InvPI" expands to "* 1.f/PI")
+PTK_DI f2 sphere2plane(f3 d) {
+    f2 uv;
+    const float a = atan2_ptk(d.z, d.x) * 1.f / PTK_PI * .5f + 1.f;
+    uv.x = a - floorf(a);
+    uv.y = gmax(atan2_ptk(d.y, sqrtf(d.x * d.x + d.z * d.z)) * 1.f / PTK_PI + 0.5f, 0.f);
+    return uv;
+}
+PTK_DI f3 env_radiance(const SceneView& S, f3 dir) { return tex_sample(S, S.env_tex, sphere2plane(dir)); }
+
 // ---- closest hit, in three pieces so that kernels can schedule them differently -----------------------------------
 // (1) analytic primitives (pathtrace.cu:211-235): wave-uniform loop, primitive records in SGPRs
 struct Analytic { float t_min; int geom; f3 P, NS; };
@@ -362,10 +415,25 @@ PTK_DI void triangle_record(const SceneView& S, int tri, float bu, float bv, flo
     const float w = 1 - bu - bv;
     f3 P = w * mk3(V.v0[0], V.v0[1], V.v0[2]) + bu * mk3(V.v1[0], V.v1[1], V.v1[2]) + bv * mk3(V.v2[0], V.v2[1], V.v2[2]);
     f3 N = w * mk3(A.n0[0], A.n0[1], A.n0[2]) + bu * mk3(A.n1[0], A.n1[1], A.n1[2]) + bv * mk3(A.n2[0], A.n2[1], A.n2[2]);
-    h.uv.x = gclamp(w * A.t0[0] + bu * A.t1[0] + bv * A.t2[0], 0.f, 1.f);
-    h.uv.y = gclamp(w * A.t0[1] + bu * A.t1[1] + bv * A.t2[1], 0.f, 1.f);
+    f2 tc; tc.x = w * A.t0[0] + bu * A.t1[0] + bv * A.t2[0]; tc.y = w * A.t0[1] + bu * A.t1[1] + bv * A.t2[1];
+    h.uv.x = gclamp(tc.x, 0.f, 1.f);
+    h.uv.y = gclamp(tc.y, 0.f, 1.f);
     h.t = t; h.p = P; h.n = normalize(N);
     h.geom = A.geomIdx; h.mat = S.geoms[A.geomIdx].materialid; h.tri = tri;
+    // normal mapping, pathtrace.cu:323-340 (sampled with the UNclamped texCoords, like the reference).  With the constant
+    // sampler (0.5,0.5,1) localNorm is exactly (0,0,1) and the branch is never taken, so only real maps are evaluated.
+    const int nt = S.mats[h.mat].normal_tex;
+    if (nt >= 0) {
+        const f3 mapped = tex_sample(S, nt, tc);
+        const f3 ln = normalize(mk3(mapped.x * 1.f - 0.5f, mapped.y * 1.f - 0.5f, mapped.z * 1.f - 0.5f));
+        f3 T = mk3(A.tangent[0], A.tangent[1], A.tangent[2]);
+        if (dot(T, T) > 1e-3f && (double)fabsf(ln.z - 1.f) > 1e-5) {
+            const f3 nrm = h.n;
+            const f3 B = normalize(cross(nrm, T));
+            T = normalize(cross(B, nrm));
+            h.n = normalize(mk3(T.x * ln.x + B.x * ln.y + nrm.x * ln.z, T.y * ln.x + B.y * ln.y + nrm.y * ln.z, T.z * ln.x + B.z * ln.y + nrm.z * ln.z));
+        }
+    }
 }
 
 // computeIntersections body (pathtrace.cu:191-343) for one ray, everything in the calling lane.  Returns rayValid.
@@ -418,6 +486,18 @@ PTK_DI bool occluded(const SceneView& S, f3 ori, f3 dir, f3 des) {
         idx = nd.b;
     }
     return false;
+}
+
+// material parameters at a hit: the four devTexSampler::linearSample(uv) calls of material.h, resolved once
+struct MatEval { int type; f3 albedo_member, albedo; float rough, metal, ior; };
+PTK_DI MatEval eval_material(const SceneView& S, const DevMaterial& m, f2 uv) {
+    MatEval e;
+    e.type = m.type; e.ior = m.ior;
+    e.albedo_member = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    e.albedo = m.albedo_tex >= 0 ? tex_sample(S, m.albedo_tex, uv) : mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+    e.rough = m.rough_tex >= 0 ? gclamp(tex_sample(S, m.rough_tex, uv).x, PTK_ROUGHNESS_MIN, PTK_ROUGHNESS_MAX) : m.rough;
+    e.metal = m.metal_tex >= 0 ? gclamp(tex_sample(S, m.metal_tex, uv).x, 0.f, 1.f) : m.metal;
+    return e;
 }
 
 // ---- shading math ---------------------------------------------------------------------------------
@@ -526,9 +606,9 @@ PTK_DI float metallic_pdf(f3 n, f3 wo, f3 wi, float rough, float metal) {     //
 struct Scatter { f3 bsdf; float pdf; f3 dir; };
 
 // Material::scatterSample, material.h:450-481.  wo = incident direction (into the surface).
-PTK_DI void scatter_sample(const DevMaterial& m, f3 n, f3 wo, Scatter& s, Rng& rng) {
+PTK_DI void scatter_sample(const MatEval& m, f3 n, f3 wo, Scatter& s, Rng& rng) {
     s.pdf = 0.f; s.bsdf = mk3(0, 0, 0); s.dir = mk3(0, 0, 0);
-    f3 albedo = mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+    f3 albedo = m.albedo;
     switch (m.type) {
     case 0: {
         s.bsdf = albedo / PTK_PI;
@@ -573,12 +653,12 @@ PTK_DI void scatter_sample(const DevMaterial& m, f3 n, f3 wo, Scatter& s, Rng& r
         s.pdf = microfacet_pdf(n, -1.f * wo, s.dir, m.rough);
         break; }
     case 4:
-        s.bsdf = mk3(m.albedo[0], m.albedo[1], m.albedo[2]); s.pdf = 1.f; break;
+        s.bsdf = m.albedo_member; s.pdf = 1.f; break;
     default: break;
     }
 }
-PTK_DI f3 mat_bsdf(const DevMaterial& m, f3 n, f3 wo, f3 wi) {       // Material::BSDF, material.h:483-501
-    f3 albedo = mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+PTK_DI f3 mat_bsdf(const MatEval& m, f3 n, f3 wo, f3 wi) {       // Material::BSDF, material.h:483-501
+    f3 albedo = m.albedo;
     switch (m.type) {
     case 0: return albedo / PTK_PI;
     case 3: return microfacet_bsdf(n, -1.f * wo, wi, albedo, m.rough);
@@ -586,7 +666,7 @@ PTK_DI f3 mat_bsdf(const DevMaterial& m, f3 n, f3 wo, f3 wi) {       // Material
     default: return mk3(0, 0, 0);
     }
 }
-PTK_DI float mat_pdf(const DevMaterial& m, f3 n, f3 wo, f3 wi) {     // Material::pdf, material.h:503-521
+PTK_DI float mat_pdf(const MatEval& m, f3 n, f3 wo, f3 wi) {     // Material::pdf, material.h:503-521
     switch (m.type) {
     case 0: return dot(wi, n) / PTK_PI;
     case 3: return microfacet_pdf(n, -1.f * wo, wi, m.rough);

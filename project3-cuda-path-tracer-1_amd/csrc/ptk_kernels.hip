@@ -335,6 +335,19 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
     }
 }
 
+// environment map on a miss (pathtrace.cu:303-311): img[pixel] += processNAN(color * env(sphere2Plane(direction)))
+__global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
+                                                         const int* __restrict__ valid, float* __restrict__ img, unsigned plane_stride) {
+    const int n = d_n ? *d_n : n_arg;
+    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= n || valid[i] != 0) return;
+    const float4 d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
+    const int pix = __float_as_int(paths.o_pix[4 * (size_t)i + 3]);
+    const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
+    float* p = img + (size_t)(pix >> 24) * plane_stride + 3 * (size_t)(pix & 0xFFFFFF);
+    p[0] += c.x; p[1] += c.y; p[2] += c.z;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // shading: PTkernel (405-498), DirectLiPTkernel (348-403), MisPTkernel (500-588) for one path.
 // `slot` is the compacted index of the path == the RNG key of the reference.  Returns rayValid.
@@ -351,11 +364,11 @@ __device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
 template <int MODE>
 __device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
     if (h.t <= 0.f) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
-    const DevMaterial& m = S.mats[h.mat];
+    const MatEval m = eval_material(S, S.mats[h.mat], h.uv);
     Rng rng = make_rng(iter, slot, depth);
     if (MODE == PTK_MODE_DIRECTLI) {
         if (m.type == PTK_MAT_LIGHT) {
-            p.col = p.col * mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+            p.col = p.col * m.albedo_member;
             p.bounces = 0;
             add_radiance(img, p.pix, nan_to_zero(p.col));
             return 0;
@@ -738,6 +751,10 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
                                     ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark);
     if (rc) return rc;
+    if (S.env_tex >= 0) {
+        k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride);
+        if ((rc = launch_rc())) return rc;
+    }
     mark(2, true);
     rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, st);
     mark(2, false);
@@ -777,7 +794,7 @@ int ptk_generate_rays(const PtkCamera* cam, int iter, int trace_depth, PtkPaths 
 }
 
 int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkHits hits, int* valid,
-                  unsigned long long* stats, void* stream) {
+                  unsigned long long* stats, float* img, void* stream) {
     if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid) return PTK_E_BADARG;
     if (n == 0) return 0;
@@ -791,8 +808,13 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
         hipError_t e = hipMalloc(&g_abi_list, sizeof(int) * (size_t)n); if (e != hipSuccess) return (int)e;
         g_abi_list_cap = n;
     }
-    return launch_intersect_stage(dev_view(*s->scene), n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
-                                  nullptr, nullptr, true, (hipStream_t)stream, [](int, bool) {});
+    const SceneView S = dev_view(*s->scene);
+    int rc = launch_intersect_stage(S, n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
+                                    nullptr, nullptr, true, (hipStream_t)stream, [](int, bool) {});
+    if (rc || !img || S.env_tex < 0) return rc;
+    if (!paths.col_pdf) return PTK_E_BADARG;
+    k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, img, 0u);
+    return launch_rc();
 }
 
 int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkHits hits_in,

@@ -3,6 +3,7 @@
 // src/scene.cpp, src/BVH.cpp, src/utilities.cpp and src/main.cpp so that the tables it produces are identical;
 // cited per function.  Pure host C++ (no HIP calls here; the upload lives in dev_scene.cpp).
 #include "scene.h"
+#include "image.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -290,6 +291,7 @@ void threadSixWays(const std::vector<FlatNode>& nodes, std::vector<GpuBVHNode>& 
 }
 
 std::map<std::string, MeshData*> g_meshPool;           // Resource::meshPool, scene.cpp:43
+std::map<std::string, image*> g_texturePool;           // Resource::texturePool, scene.cpp:44
 
 } // namespace
 
@@ -359,6 +361,20 @@ MeshData* Resource::loadObj(const std::string& filename, const int geomIdx, std:
 void Resource::clear() {
     for (auto& kv : g_meshPool) delete kv.second;
     g_meshPool.clear();
+    for (auto& kv : g_texturePool) delete kv.second;
+    g_texturePool.clear();
+}
+
+// Resource::loadTexture, scene.cpp:465-477.  nullptr + empty *err: no such file (the caller falls back to numbers);
+// nullptr + message: the file exists but cannot be decoded by this build (PNG 8-bit and Radiance .hdr only).
+image* Resource::loadTexture(const std::string& filename, float gamma, std::string* err) {
+    auto hit = g_texturePool.find(filename);
+    if (hit != g_texturePool.end()) return hit->second;
+    { std::ifstream probe(filename.c_str(), std::ios::binary); if (!probe.good() || probe.peek() == EOF) return nullptr; }   // no such file (or a directory)
+    image* tex = new image(filename, gamma);
+    if (!tex->ok()) { if (err) *err = "cannot decode image " + filename + ": " + tex->error; delete tex; return nullptr; }
+    g_texturePool[filename] = tex;
+    return tex;
 }
 
 // ---------------------------------------------------------------- Scene (scene.cpp:47-337)
@@ -377,7 +393,7 @@ Scene::Scene(const std::string& filename, int res_w, int res_h, int depth) : ovr
         if (tk[0] == "MATERIAL" && tk.size() > 1) rc = loadMaterial(in, tk[1]);
         else if (tk[0] == "OBJECT" && tk.size() > 1) rc = loadGeom(in, tk[1]);
         else if (tk[0] == "CAMERA") rc = loadCamera(in);
-        else if (tk[0] == "ENV") { error = "ENV environment maps are not supported (SURVEY 8f-1)"; rc = -2; }
+        else if (tk[0] == "ENV" && tk.size() > 1) { envMapID = loadTexture(tk[1]); rc = envMapID == -2 ? -2 : 1; if (envMapID < 0) envMapID = -1; }
         if (rc == -2) return;
     }
     ok = true;
@@ -405,19 +421,31 @@ int Scene::loadMaterial(std::istream& in, const std::string& name) {  // scene.c
             for (int k = 0; k < 5; ++k) if (tk[1] == kTypeNames[k]) m.type = (Material::Type)k;
         } else if (key == "ALBEDO" || key == "METALLIC" || key == "ROUGHNESS") {
             // The reference first tries the value token as an image file and falls back to numbers (scene.cpp:276-297).
-            if (tk.size() < 2 || !isPlainNumber(tk[1])) { error = "texture maps are not supported: " + line; return -2; }
+            if (tk.size() < 2) continue;
+            const int id = loadTexture(tk[1]);
+            if (id == -2) return -2;
             if (key == "ALBEDO") {
-                if (tk.size() < 4) { error = "ALBEDO needs three numbers: " + line; return -2; }
-                m.albedo = toV3(tk); m.albedoSampler = m.albedo;
+                m.albedoMapID = id;
+                if (id < 0) {
+                    if (tk.size() < 4) { error = "ALBEDO needs three numbers: " + line; return -2; }
+                    m.albedo = toV3(tk); m.albedoSampler = m.albedo;
+                }
             } else if (key == "METALLIC") {
-                m.metallic = toF(tk[1]); m.metallicSampler = m.metallic;
+                m.metallicMapID = id;
+                if (id < 0) { m.metallic = toF(tk[1]); m.metallicSampler = m.metallic; }
             } else {
-                const double r = std::atof(tk[1].c_str());
-                m.roughness = (float)(r > 1e-3 ? r : 1e-3);             // glm::max(atof(...), ROUGHNESS_MIN), doubles
-                m.roughnessSampler = m.roughness;
+                m.roughnessMapID = id;
+                if (id < 0) {
+                    const double r = std::atof(tk[1].c_str());
+                    m.roughness = (float)(r > 1e-3 ? r : 1e-3);         // glm::max(atof(...), ROUGHNESS_MIN), doubles
+                    m.roughnessSampler = m.roughness;
+                }
             }
-        } else if (key == "NORMAL") {
-            error = "normal maps are not supported: " + line; return -2;
+        } else if (key == "NORMAL" && tk.size() > 1) {
+            // scene.cpp:303-311: the constant sampler (0.5,0.5,1) is the default either way; a loaded map is bound at upload
+            const int id = loadTexture(tk[1]);
+            if (id == -2) return -2;
+            m.normalMapID = id;
         } else if (key == "IOR" && tk.size() > 1) {
             m.ior = toF(tk[1]);
         }
@@ -425,6 +453,15 @@ int Scene::loadMaterial(std::istream& in, const std::string& name) {  // scene.c
     materialNameMap[name] = (int)materials.size();
     materials.push_back(m);
     return 1;
+}
+
+int Scene::loadTexture(const std::string& fileName, float gamma) {     // scene.cpp:318-337
+    std::string err;
+    image* tex = Resource::loadTexture(resolvePath(fileName), gamma, &err);
+    if (!tex) { if (!err.empty()) { error = err; return -2; } return -1; }
+    for (size_t i = 0; i < textures.size(); ++i) if (textures[i] == tex) return (int)i;      // textureIdMap
+    textures.push_back(tex);
+    return (int)textures.size() - 1;
 }
 
 int Scene::loadGeom(std::istream& in, const std::string& name) {      // scene.cpp:83-163

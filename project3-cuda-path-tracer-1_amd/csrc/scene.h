@@ -58,13 +58,14 @@ struct RenderState {                                          // sceneStructs.h:
     std::string imageName;
 };
 
-class Material {                                              // material.h:28-38, 524-538 (constant samplers only)
+class Material {                                              // material.h:28-38, 524-538
 public:
     enum Type { Lambertian, MetallicWorkflow, Dielectric, Microfacet, Light };
     Type type = Lambertian;                                   // no default in the reference; 0 in practice
     ptk::vec3 albedo = ptk::vec3(1.f);
     float roughness = .0f, metallic = .0f, ior = 1.5f;
-    // devTexSampler::fixVal of the four samplers (image.h:88-110); textures are not supported
+    int albedoMapID = -1, metallicMapID = -1, roughnessMapID = -1, normalMapID = -1;     // index into Scene::textures
+    // devTexSampler::fixVal of the samplers (image.h:88-110), used when the corresponding MapID is < 0
     ptk::vec3 albedoSampler;          // default devTexSampler(): fixVal(0)
     float roughnessSampler = 0.f, metallicSampler = 0.f;
 };
@@ -90,6 +91,7 @@ public:
 };
 
 class MeshData { public: std::vector<Triangle> triangles; };  // scene.h:101-107
+class image;                                                  // image.h
 
 class Scene;
 
@@ -105,6 +107,9 @@ public:
     void* dev_triv = nullptr;         // ptk::DevTriV[]
     void* dev_tria = nullptr;         // ptk::DevTriA[]
     void* dev_lights = nullptr;       // ptk::DevLight[]
+    void* dev_textures = nullptr;     // ptk::DevTex[]          (devTexObj, image.h:53-86)
+    void* dev_texture_data = nullptr; // float[3 * total texels] (dev_texture_data, scene.cpp:575-590)
+    int tex_num = 0, envMapID = -1;
     bool uploaded = false;
 };
 
@@ -128,6 +133,8 @@ public:
     std::map<std::string, int> materialNameMap;
     std::vector<Triangle> triangles;
     std::vector<lightPrim> lights;
+    std::vector<image*> textures;                             // scene.h:72 (owned by Resource's texture pool)
+    int envMapID = -1;                                        // scene.h:76
     std::vector<GpuBVHNode> gpuBVHNodes;                      // 6 * bvhSize (direction-ordered copies)
     int bvhSize = 0;
     DevScene tempDevScene;
@@ -140,6 +147,7 @@ private:
     int loadMaterial(std::istream& in, const std::string& name);
     int loadGeom(std::istream& in, const std::string& name);
     int loadCamera(std::istream& in);
+    int loadTexture(const std::string& fileName, float gamma = 1.f);   // scene.cpp:318-337; -1 = not an image, -2 = undecodable
     std::string resolvePath(std::string p) const;
     std::string sceneDir;
     int ovrW, ovrH, ovrDepth;
@@ -147,5 +155,6 @@ private:
 
 namespace Resource {                                          // scene.h:88-98
     MeshData* loadObj(const std::string& filename, const int geomIdx, std::string* err);
+    image* loadTexture(const std::string& filename, float gamma, std::string* err);   // scene.cpp:465-477 (texturePool)
     void clear();
 }

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
 
 GEOM_DT = np.dtype([("type", "<i4"), ("materialid", "<i4"), ("transform", "<f4", 16), ("inverseTransform", "<f4", 16), ("invTranspose", "<f4", 16)])
-MATERIAL_DT = np.dtype([("type", "<i4"), ("albedo", "<f4", 3), ("albedo_s", "<f4", 3), ("rough_s", "<f4"), ("metal_s", "<f4"), ("ior", "<f4")])
+MATERIAL_DT = np.dtype([("type", "<i4"), ("albedo", "<f4", 3), ("albedo_s", "<f4", 3), ("rough_s", "<f4"), ("metal_s", "<f4"), ("ior", "<f4"),
+                        ("albedoMapID", "<i4"), ("metallicMapID", "<i4"), ("roughnessMapID", "<i4"), ("normalMapID", "<i4")])
 TRIANGLE_DT = np.dtype([("v", "<f4", 9), ("n", "<f4", 9), ("tex", "<f4", 6), ("tangent", "<f4", 3), ("bitangent", "<f4", 3), ("geomIdx", "<i4")])
 BVHNODE_DT = np.dtype([("pMin", "<f4", 3), ("pMax", "<f4", 3), ("start", "<i4"), ("end", "<i4"), ("miss", "<i4"), ("hit", "<i4")])
 LIGHT_DT = np.dtype([("geomID", "<i4"), ("triangleID", "<i4"), ("type", "<i4")])
@@ -39,6 +40,10 @@ L.orc_scene_free.argtypes = [vp]
 L.orc_scene_error.restype = C.c_char_p; L.orc_scene_error.argtypes = [vp]
 for _n in ("counts", "get_geoms", "get_materials", "get_triangles", "get_bvh", "get_lights", "get_camera"):
     getattr(L, "orc_scene_" + _n).argtypes = [vp, vp]
+L.orc_scene_texture_path.restype = C.c_char_p; L.orc_scene_texture_path.argtypes = [vp, ci]
+L.orc_scene_set_texture.argtypes = [vp, ci, ci, ci, vp]
+L.orc_intersect_env.argtypes = [vp, ci, vp, vp, vp, vp]
+L.orc_ptk_atan2_array.argtypes = [vp, vp, ci, vp]
 L.orc_utilhash.restype = C.c_uint32; L.orc_utilhash.argtypes = [C.c_uint32]
 L.orc_seed_hash.restype = C.c_uint32; L.orc_seed_hash.argtypes = [ci, ci, ci]
 L.orc_rng_uniforms.argtypes = [ci, ci, ci, ci, vp]
@@ -81,10 +86,17 @@ class Scene:
         if err:
             msg = err.decode(); L.orc_scene_free(self.h); self.h = None
             raise RuntimeError(msg)
-        c = np.zeros(9, np.int32); L.orc_scene_counts(self.h, c.ctypes.data)
+        c = np.zeros(11, np.int32); L.orc_scene_counts(self.h, c.ctypes.data)
         (self.n_geoms, self.n_materials, self.n_triangles, self.bvh_size, self.n_lights,
-         self.trace_depth, self.iterations, self.width, self.height) = (int(x) for x in c)
+         self.trace_depth, self.iterations, self.width, self.height, self.n_textures, self.env_map_id) = (int(x) for x in c)
         self.P = self.width * self.height
+        # the oracle has no image decoder: the harness decodes (PIL / image_ref.py) and hands the texels over
+        import image_ref
+        self.texture_data = []
+        for i in range(self.n_textures):
+            tex = image_ref.load_texture(L.orc_scene_texture_path(self.h, i).decode())
+            self.texture_data.append(tex)
+            L.orc_scene_set_texture(self.h, i, tex.shape[1], tex.shape[0], tex.ctypes.data)
 
     def _table(self, fn, dt, n):
         out = np.zeros(n, dt)
@@ -102,10 +114,11 @@ class Scene:
     def generate_rays(self, it):
         p = np.zeros(self.P, PATH_DT); L.orc_generate_rays(self.h, it, p.ctypes.data); return p
 
-    def intersect(self, paths):
+    def intersect(self, paths, img=None):
+        """img (optional, float32 [P,3]): ENV-map radiance of the misses is added to it (pathtrace.cu:303-311)"""
         n = len(paths); paths = np.ascontiguousarray(paths)
         isects = np.zeros(n, ISECT_DT); valid = np.zeros(n, np.int32)
-        L.orc_intersect(self.h, n, paths.ctypes.data, isects.ctypes.data, valid.ctypes.data)
+        L.orc_intersect_env(self.h, n, paths.ctypes.data, isects.ctypes.data, valid.ctypes.data, img.ctypes.data if img is not None else None)
         return isects, valid
 
     def shade(self, mode, it, depth, isects, paths, img):

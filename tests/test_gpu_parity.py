@@ -66,18 +66,13 @@ def test_generate_rays(ptk, orc, torch_cuda):
             _eq_fields(got, o.generate_rays(it), what=f"{name} iter {it}")
 
 
-@pytest.mark.parametrize("name,res,depth,mode", CASES)
-def test_kernels_step_by_step(ptk, orc, torch_cuda, name, res, depth, mode):
-    """Replays pathtrace()'s loop with the kernel-level entry points (ptk_generate_rays / ptk_intersect / ptk_compact /
-    ptk_shade) and checks every intermediate stream against the oracle's kernel restatements at every bounce."""
-    torch = torch_cuda
-    m = MODES[mode]
-    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth).upload()
-    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+def _step_by_step(ptk, orc, torch, path, res, depth, m, iters=(1, 2)):
+    s = ptk.Scene(path, res=res, depth=depth).upload()
+    o = orc.Scene(path, res=res, depth=depth)
     P = o.P
     img_ref = np.zeros((P, 3), np.float32)
     img = torch.zeros((P, 3), dtype=torch.float32, device="cuda")
-    for it in (1, 2):
+    for it in iters:
         ref_paths = o.generate_rays(it)
         A = ptk.new_paths(P); B = ptk.new_paths(P)
         HA = ptk.new_paths(P); HB = ptk.new_paths(P)
@@ -86,15 +81,16 @@ def test_kernels_step_by_step(ptk, orc, torch_cuda, name, res, depth, mode):
         ptk.generate_rays(s, it, A)
         n = P; d = 0
         while n > 0:
-            # intersect
-            ptk.intersect(s, n, A, HA, valid)
-            ref_is, ref_valid = o.intersect(ref_paths)
+            # intersect (with an ENV map the misses add their environment radiance to img, pathtrace.cu:303-311)
+            ptk.intersect(s, n, A, HA, valid, img=img)
+            ref_is, ref_valid = o.intersect(ref_paths, img_ref)
             v = valid[:n].cpu().numpy()
             assert np.array_equal(v, ref_valid), f"rayValid differs at bounce {d}"
             got_is = orc.isects_from_soa(*[h[:n].cpu().numpy() for h in HA])
             hitm = ref_valid.astype(bool)
             _eq_fields(got_is[hitm], ref_is[hitm], what=f"hit bounce {d}")
             assert (got_is["t"][~hitm] == -1).all()
+            assert np.array_equal(img.cpu().numpy(), img_ref), f"radiance differs after intersect of bounce {d}"
             # compact #1 (drop misses), both streams
             ptk.compact(n, valid, A, HA, B, HB, cnt)
             ref_paths, ref_is = orc.compact(ref_valid, ref_paths, ref_is)
@@ -116,6 +112,41 @@ def test_kernels_step_by_step(ptk, orc, torch_cuda, name, res, depth, mode):
             A, B = B, A
             d += 1
         assert d <= o.trace_depth
+    return img_ref
+
+
+@pytest.mark.parametrize("name,res,depth,mode", CASES)
+def test_kernels_step_by_step(ptk, orc, torch_cuda, name, res, depth, mode):
+    """Replays pathtrace()'s loop with the kernel-level entry points (ptk_generate_rays / ptk_intersect / ptk_compact /
+    ptk_shade) and checks every intermediate stream against the oracle's kernel restatements at every bounce."""
+    _step_by_step(ptk, orc, torch_cuda, os.path.join(SC, name), res, depth, MODES[mode])
+
+
+@pytest.mark.parametrize("mode,env", [("BSDF", True), ("MIS", True), ("MIS", False), ("DIRECT", True)])
+def test_textured_scene(ptk, orc, torch_cuda, tmp_path, mode, env):
+    """SURVEY §8f-1: albedo / roughness / metallic / normal maps (bilinear devTexObj::linearSample, TBN normal mapping) and
+    the ENV map on misses, on a synthetic uv-mapped scene: kernel by kernel, then the render loop with iterations in flight."""
+    import texture_scene
+    path = texture_scene.make(tmp_path, env=env)
+    m = MODES[mode]
+    ref1 = _step_by_step(ptk, orc, torch_cuda, path, None, -1, m, iters=(1,))
+    assert ref1.sum() > 0
+    s = ptk.Scene(path); o = orc.Scene(path)
+    lanes = 2
+    r = ptk.Renderer(s, m, in_flight=lanes)
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    for it in (1, 2, 3, 4):
+        r.iterate(it)
+        _, live = o.pathtrace(m, it, planes[(it - 1) % lanes])
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (it, counts, live)
+    img = r.image(); r.close()
+    assert np.array_equal(img, planes[0] + planes[1])
+    assert np.array_equal(planes[0] if False else _first_iteration(o, m), ref1)
+
+
+def _first_iteration(o, m):
+    img = np.zeros((o.P, 3), np.float32); o.pathtrace(m, 1, img); return img
 
 
 @pytest.mark.parametrize("name,res,depth,mode", CASES)
