@@ -168,6 +168,8 @@ int ptk_set_samples_per_launch(int spp);
  * is counting-sorted by material type in LDS before shading, to cut BSDF-switch divergence (default 256; measured gain on MI355X is small, 1-5 %).  Every path keeps
  * its own RNG key and state, so results are identical. */
 int ptk_set_shade_binning(int block);
+/* Threads per block of the fused bounce kernel (pipeline 3): 256 (default) or 512.  Identical results. */
+int ptk_set_fused_block(int threads);
 /* 1: replay every iteration from a hipGraph captured once per lane (the kernels then read the iteration number from device
  * memory); 0 (default): launch the kernels one by one.  Identical results; cuts the host cost per iteration. */
 int ptk_set_graph_replay(int on);
@@ -189,12 +191,15 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 /* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
-/* Pipeline selection (A/B comparisons; all produce identical results).  Only scenes with triangles differ:
- *   0 = default: analytic primitives + BVH root-box test per ray, stable compaction of the rays that enter the root box into
- *       a work list, BVH walk over the list (one listed ray per lane), finalize.  ~9 % faster than 1 on the bunny scene with
- *       3 iterations in flight (denser waves in the divergent walk);
- *   1 = the BVH is walked inside the intersect kernel for every ray, one ray per lane;
- *   2 = like 1 with two rays per lane (measured slower). */
+/* Pipeline selection (A/B comparisons; all produce identical results):
+ *   0 = staged, three kernel classes per bounce (intersect / shade / scatter) with device-resident counts.  Scenes with
+ *       triangles run the work-list BVH layout (analytic primitives + root-box test, stable compaction of the rays that enter
+ *       the root box, BVH walk over the list, finalize);
+ *   1 = staged, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
+ *   2 = like 1, and analytic primitives are tested with wave-uniform loops over every primitive instead of the LDS-staged
+ *       per-lane candidate loops;
+ *   3 = fused: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans; the hit
+ *       record never leaves registers, one third of the staged layout's memory traffic). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 

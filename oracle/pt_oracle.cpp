@@ -1466,6 +1466,19 @@ float orc_sphere_test(const void* geom, const float* o, const float* d, float* P
     v3 p, n; float t = sphereIntersectionTest(*(const Geom*)geom, r, p, n);
     P[0] = p.x; P[1] = p.y; P[2] = p.z; N[0] = n.x; N[1] = n.y; N[2] = n.z; return t;
 }
+// batch forms of the two probes above (n rays against one primitive): t only
+void orc_box_test_array(const void* geom, const float* o, const float* d, int n, float* t) {
+    for (int i = 0; i < n; ++i) {
+        Ray r; r.origin = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.direction = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        v3 p, nn; t[i] = boxIntersectionTest(*(const Geom*)geom, r, p, nn);
+    }
+}
+void orc_sphere_test_array(const void* geom, const float* o, const float* d, int n, float* t) {
+    for (int i = 0; i < n; ++i) {
+        Ray r; r.origin = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.direction = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        v3 p, nn; t[i] = sphereIntersectionTest(*(const Geom*)geom, r, p, nn);
+    }
+}
 int orc_aabb_test(const float* pmin, const float* pmax, const float* o, const float* d, float* t) {
     Ray r; r.origin = v3(o[0], o[1], o[2]); r.direction = v3(d[0], d[1], d[2]);
     return aabbIntersectP(v3(pmin[0], pmin[1], pmin[2]), v3(pmax[0], pmax[1], pmax[2]), r, *t) ? 1 : 0;

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
-    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning",
+    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_fused_block",
 ]
 
 
@@ -131,6 +131,7 @@ def _load() -> C.CDLL:
     lib.ptk_set_graph_replay.argtypes = [ci]
     lib.ptk_set_samples_per_launch.argtypes = [ci]
     lib.ptk_set_shade_binning.argtypes = [ci]
+    lib.ptk_set_fused_block.argtypes = [ci]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
     lib.ptk_profile_end.argtypes = [vp, vp]
     lib.ptk_enable_traversal_stats.argtypes = [ci]

@@ -11,7 +11,9 @@
 //   DevTriA[T]       64 B each : vertex normals, texcoords, geomIdx (touched once per ray, for the final hit)
 #include "ptk_internal.h"
 #include "image.h"
+#include <cmath>
 #include <cstring>
+#include <limits>
 
 using namespace ptk;
 
@@ -48,6 +50,53 @@ int DevScene::initiate(Scene& scene) {
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
             if (r != c && (s.inverseTransform.at(c, r) != 0.f || s.transform.at(c, r) != 0.f || s.invTranspose.at(c, r) != 0.f)) diag = false;
         g[i].diag = diag ? 1 : 0;
+    }
+    // padded world-space bounds + per-chunk type masks for the conservative candidate test (ptk_device.hpp: analytic_candidates)
+    std::vector<DevGeomBox> gb(scene.geoms.size());
+    std::vector<DevGeomMask> gm((scene.geoms.size() + 31) / 32 + 1, DevGeomMask{0u, 0u, 0u, 0u});
+    for (size_t i = 0; i < gb.size(); ++i) {
+        const Geom& s = scene.geoms[i];
+        const float inf = std::numeric_limits<float>::infinity();
+        DevGeomBox b{{-inf, inf, -inf, inf, -inf, inf}, 0.f, 0.f};
+        bool finite = true;
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r)
+            finite = finite && std::isfinite(s.transform.at(c, r)) && std::isfinite(s.inverseTransform.at(c, r)) && std::isfinite(s.invTranspose.at(c, r));
+        if (finite) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, mag = 0.0;
+            for (int k = 0; k < 8; ++k) {
+                const double c[3] = {(k & 1) ? 0.5 : -0.5, (k & 2) ? 0.5 : -0.5, (k & 4) ? 0.5 : -0.5};
+                for (int r = 0; r < 3; ++r) {
+                    const double w = (double)s.transform.at(0, r) * c[0] + (double)s.transform.at(1, r) * c[1] + (double)s.transform.at(2, r) * c[2] + (double)s.transform.at(3, r);
+                    lo[r] = w < lo[r] ? w : lo[r]; hi[r] = w > hi[r] ? w : hi[r];
+                    mag = std::fabs(w) > mag ? std::fabs(w) : mag;
+                }
+            }
+            const double pad = (double)PTK_CAND_ABS + (double)PTK_CAND_REL * mag;
+            for (int r = 0; r < 3; ++r) {
+                b.s[2 * r] = std::nextafter((float)(lo[r] - pad), -inf);
+                b.s[2 * r + 1] = std::nextafter((float)(hi[r] + pad), inf);
+            }
+            if (s.type == SPHERE) {                      // PTK_CAND_QUAD: per-ray pad qa + qb * |o|^2
+                double smin = 1e300, smax = 0.0, cc = 0.0;
+                for (int c = 0; c < 3; ++c) {            // column norms of the 3x3 part = the scale factors (T * R * S)
+                    double nrm = 0.0;
+                    for (int r = 0; r < 3; ++r) nrm += (double)s.transform.at(c, r) * (double)s.transform.at(c, r);
+                    nrm = std::sqrt(nrm);
+                    smin = nrm < smin ? nrm : smin; smax = nrm > smax ? nrm : smax;
+                    cc += (double)s.transform.at(3, c) * (double)s.transform.at(3, c);
+                }
+                const double Q = smin > 0.0 ? (double)PTK_CAND_QUAD * smax / (smin * smin) : (double)inf;
+                b.qa = std::nextafter((float)(2.0 * Q * cc), inf);
+                b.qb = std::nextafter((float)(2.0 * Q), inf);
+                if (!std::isfinite(b.qa) || !std::isfinite(b.qb)) { b = DevGeomBox{{-inf, inf, -inf, inf, -inf, inf}, 0.f, 0.f}; }
+            }
+        }
+        gb[i] = b;
+        DevGeomMask& mk = gm[i / 32];
+        const unsigned bit = 1u << (i % 32);
+        if (s.type == CUBE) mk.cube |= bit;
+        if (s.type == SPHERE) mk.sphere |= bit;
+        if (g[i].diag) mk.diag |= bit;
     }
     std::vector<DevMaterial> m(scene.materials.size());
     for (size_t i = 0; i < m.size(); ++i) {
@@ -102,6 +151,8 @@ int DevScene::initiate(Scene& scene) {
 
     int rc;
     if ((rc = upload(&dev_geoms, g))) return rc;
+    if ((rc = upload(&dev_gbox, gb))) return rc;
+    if ((rc = upload(&dev_gmask, gm))) return rc;
     if ((rc = upload(&dev_materials, m))) return rc;
     if ((rc = upload(&dev_nodes, nodes))) return rc;
     if ((rc = upload(&dev_trie, te))) return rc;
@@ -117,7 +168,7 @@ int DevScene::initiate(Scene& scene) {
 }
 
 void DevScene::destroy() {
-    void** ptrs[] = {&dev_geoms, &dev_materials, &dev_nodes, &dev_trie, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
+    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_trie, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     uploaded = false;
 }

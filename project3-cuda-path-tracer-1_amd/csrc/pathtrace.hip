@@ -85,6 +85,7 @@ int context_free() {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
+        dfree(l.ws.ticket); dfree(l.ws.epoch); dfree(l.ws.st_hit); dfree(l.ws.st_live);
         dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
         if (l.graph) (void)hipGraphDestroy(l.graph);
@@ -114,7 +115,7 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.p_mat, 4 * (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.uv_ids, 4 * (size_t)g.capacity))) return rc;
-    const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;       // +2: k_intersect2 writes aggregates in pairs
+    const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;
     if ((rc = dalloc(&l.ws.agg_a, blocks))) return rc;
     if ((rc = dalloc(&l.ws.agg_b, blocks))) return rc;
     if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
@@ -123,10 +124,23 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.queue, 1))) return rc;
     if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
+    if ((rc = dalloc(&l.ws.ticket, 1))) return rc;
+    if ((rc = dalloc(&l.ws.epoch, 1))) return rc;
+    if ((rc = dalloc(&l.ws.st_hit, blocks))) return rc;
+    if ((rc = dalloc(&l.ws.st_live, blocks))) return rc;
+    {
+        const unsigned one = 1u;                 // tag 0 never matches: the zeroed tables read as "not published"
+        if ((e = hipMemsetAsync(l.ws.ticket, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
+        if ((e = hipMemcpyAsync(l.ws.epoch, &one, sizeof(unsigned), hipMemcpyHostToDevice, l.stream)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(l.ws.st_hit, 0, sizeof(unsigned long long) * blocks, l.stream)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(l.ws.st_live, 0, sizeof(unsigned long long) * blocks, l.stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) return (int)e;
+    }
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
     l.ws.inline_bvh = (g.pipeline != 0);
+    l.ws.fused = (g.pipeline == 3);
     l.ws.capacity = g.capacity;
     l.last_iter = 0;
     return 0;
@@ -194,7 +208,11 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     PtkPaths cur = L.bufA, nxt = L.bufB;
     for (int depth = 0; depth < g.traceDepth; ++depth) {
         const bool last = depth == g.traceDepth - 1;
-        if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
+        if (ws.fused) {
+            prof_mark(1, true);      // the fused kernel is reported in the intersect class
+            rc = launch_bounce_fused(S, mode, iter, depth, g.capacity, cur, nxt, L.plane, ws, L.stream, last);
+            prof_mark(1, false);
+        } else if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
         else rc = launch_bounce_staged(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, last);
         if (rc) return rc;
         PtkPaths t = cur; cur = nxt; nxt = t;
@@ -295,6 +313,7 @@ int ptk_set_iterations_in_flight(int lanes) {
 /* Shading kernel layout: 0 = one path per thread in path order; 256 / 512 / 1024 = paths of a block of that many consecutive
  * paths are counting-sorted by material type before shading (default 256).  Identical results. */
 int ptk_set_shade_binning(int block) { if (block != 0 && block != 256 && block != 512 && block != 1024) return PTK_E_BADARG; set_shade_bin(block); return 0; }
+int ptk_set_fused_block(int threads) { if (threads != 256 && threads != 512) return PTK_E_BADARG; set_fused_block(threads); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
 int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
 
@@ -369,10 +388,10 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     return x + y * W;
 }
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 2) return PTK_E_BADARG;
+    if (which < 0 || which > 3) return PTK_E_BADARG;
     g.pipeline = which;
-    for (Lane& l : g.lanes) l.ws.inline_bvh = (which != 0);
-    set_rays_per_lane(which == 2 ? 2 : 1);
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0); l.ws.fused = (which == 3); }
+    set_uniform_analytic(which == 2);
     return 0;
 }
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the

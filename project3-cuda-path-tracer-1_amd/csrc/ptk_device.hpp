@@ -108,6 +108,22 @@ struct DevGeom {
     float invT[9];      // upper 3x3 of invTranspose, row-major
     int diag;           // 1: the 3x3 parts of inv, fwd and invT are diagonal (all off-diagonal entries are +-0)
 };
+// World-space bounds of one analytic primitive for the conservative candidate test (analytic_candidates), 8 dwords, slab
+// pairs adjacent: {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, -, -}.  The box encloses the transformed unit cube, grown on the host
+// by PTK_CAND_ABS + PTK_CAND_REL * max|corner coordinate| (dev_scene.hip).  A primitive whose transform is not finite
+// gets (-inf, +inf) slabs (always a candidate).
+struct DevGeomBox { float s[6]; float qa, qb; };      // spheres: extra pad qa + qb * |origin|^2 (see PTK_CAND_QUAD), cubes 0
+// Per chunk of 32 primitives: bit k set <=> primitive base + k is a cube / a sphere / has diagonal 3x3 transforms.
+struct DevGeomMask { unsigned cube, sphere, diag, pad; };
+// Margins of the candidate test.  Measured need (tests/test_candidate_margin.py: adversarial grazing rays, exact fp32 test
+// vs this test): no exact hit is ever culled from REL = 1e-7 on; shipped values are 20x that.
+#define PTK_CAND_ABS 1e-5f
+#define PTK_CAND_REL 2e-6f
+// Spheres only: the exact test's radicand vd*vd - (dot(o,o) - 0.25) cancels catastrophically for distant origins; it accepts
+// rays that pass the unit sphere at up to ~3.6e-7 * |o_obj|^2 (object units) — quadratic in the distance.  The box of a sphere
+// is therefore grown per ray by QUAD * s_max / s_min^2 * |o - c|^2, bounded by 2 (|o|^2 + |c|^2): qa = 2 Q |c|^2, qb = 2 Q.
+// Measured need: QUAD = 3e-7; shipped 13x that.
+#define PTK_CAND_QUAD 4e-6f
 struct DevMaterial {    // 16 dwords
     int type;
     float albedo[3], albedo_s[3];
@@ -131,6 +147,10 @@ struct DevLight { int geomID, triangleID, type; };
 
 struct SceneView {
     const DevGeom* geoms;        int n_geoms;
+    const DevGeomBox* gbox;      // [n_geoms]
+    const DevGeomMask* gmask;    // [ceil(n_geoms / 32)]
+    int lds_geoms;               // > 0: kernels stage the transforms of all n_geoms primitives in LDS (stage_geoms) and run the
+                                 // candidate loops; 0: wave-uniform loops over every primitive (scalar loads)
     const DevMaterial* mats;     int n_mats;
     const DevNode* nodes;        int bvh_size;   // [6][bvh_size]
     const DevTriE* trie;         // traversal form of the triangles
@@ -151,6 +171,32 @@ PTK_DI DevGeom load_geom_uniform(const DevGeom* base, int i) {
     uint32_t* dst = reinterpret_cast<uint32_t*>(&g);
 #pragma unroll
     for (int k = 0; k < (int)(sizeof(DevGeom) / 4); ++k) dst[k] = p[k];
+    return g;
+#else
+    return base[i];
+#endif
+}
+
+PTK_DI DevGeomBox load_gbox_uniform(const DevGeomBox* base, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t __attribute__((address_space(4)))* cptr;
+    cptr p = (cptr)(const uint32_t*)(base + i);
+    DevGeomBox g;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&g);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(DevGeomBox) / 4); ++k) dst[k] = p[k];
+    return g;
+#else
+    return base[i];
+#endif
+}
+
+PTK_DI DevGeomMask load_gmask_uniform(const DevGeomMask* base, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t __attribute__((address_space(4)))* cptr;
+    cptr p = (cptr)(const uint32_t*)(base + i);
+    DevGeomMask g;
+    g.cube = p[0]; g.sphere = p[1]; g.diag = p[2]; g.pad = 0u;
     return g;
 #else
     return base[i];
@@ -191,10 +237,26 @@ PTK_DI f3 xform_nrm_d(const float* m, f3 v, int diag) {
 }
 
 // ---- primitives -----------------------------------------------------------------------------------
+// The part of a primitive record the exact tests read (inverseTransform, transform, diag), as a per-lane register copy.
+// Staged form: kernels copy dwords [2, 26) of every DevGeom into LDS once per block (stage_geoms), 24 floats = 96 B per
+// primitive, and each lane fetches the record of ITS current candidate with six ds_read_b128.
+struct GeomXf { float inv[12], fwd[12]; int diag; };
+#define PTK_XF_FLOATS 24
+#define PTK_LDS_GEOMS_MAX 512          // 48 KB of LDS; larger scenes use the wave-uniform loops
+struct GeomStage { const float* xf; bool on; };
+PTK_DI GeomXf load_xf(const float* xf, int i, int diag) {
+    GeomXf g;
+    const float* p = xf + (size_t)i * PTK_XF_FLOATS;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { g.inv[k] = p[k]; g.fwd[k] = p[12 + k]; }
+    g.diag = diag;
+    return g;
+}
 // boxIntersectionTest, intersections.h:48-90.  Returns world-space distance or -1.
 // The normal is NOT computed here: `ns` receives the object-space vector n with N = normalize(invTranspose * n), so the
 // caller evaluates it once for the primitive that wins (the reference evaluates it for every candidate and discards it).
-PTK_DI float box_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& ns) {
+template <class G>
+PTK_DI float box_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
     f3 qo = xform_point_d(g.inv, ro, g.diag);
     f3 qd = normalize(xform_dir_d(g.inv, rd, g.diag));
     float tmin = -1e38f, tmax = 1e38f;
@@ -220,7 +282,8 @@ PTK_DI float box_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& ns) {
 }
 
 // sphereIntersectionTest, intersections.h:102-144 (normal deferred like box_test: ns = object-space hit point)
-PTK_DI float sphere_test(const DevGeom& g, f3 ro, f3 rd, f3& P, f3& ns) {
+template <class G>
+PTK_DI float sphere_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
     f3 o = xform_point_d(g.inv, ro, g.diag);
     f3 d = normalize(xform_dir_d(g.inv, rd, g.diag));
     float vd = dot(o, d);
@@ -361,15 +424,88 @@ PTK_DI f3 env_radiance(const SceneView& S, f3 dir) { return tex_sample(S, S.env_
 // ---- closest hit, in three pieces so that kernels can schedule them differently -----------------------------------
 // (1) analytic primitives (pathtrace.cu:211-235): wave-uniform loop, primitive records in SGPRs
 struct Analytic { float t_min; int geom; f3 P, NS; };
-PTK_DI void analytic_closest(const SceneView& S, f3 ro, f3 rd, Analytic& a) {
+
+// Conservative candidate test.  The reference runs the exact object-space test of EVERY primitive for every ray
+// (pathtrace.cu:211-235); a test that misses has no side effect, so primitives that provably miss can be skipped.
+// A primitive is a candidate unless the ray misses its padded world-space box: slab test t = (b - o') * (1/d) with
+// approximate reciprocals (packed subtract + packed multiply, two planes per instruction), the box grown on the host
+// (DevGeomBox) and the origin here by PTK_CAND_REL * (1 + |origin|_inf).  The exact test's rounding moves a hit/miss
+// decision by ~1e-7 relative to those magnitudes (measured, see PTK_CAND_REL).  Direction components that are 0 or
+// denormal give +-inf slabs of the right sign (the subtraction comes first, so there is no inf - inf); the only NaN is
+// 0 * inf — shifted origin exactly on a padded plane, direction parallel to it — which the IEEE min/max turn into a
+// miss, correct because the real primitive lies a margin inside.  Rays with NaN components never produce an accepted
+// hit in the exact test either (t > 0 fails).  Output: one bit per primitive of the chunk [base, base+n), n <= 32.
+struct Cand { unsigned cube, sphere, diag; };
+typedef float ptk_v2f __attribute__((ext_vector_type(2)));
+PTK_DI Cand analytic_candidates(const SceneView& S, int base, int n, f3 ro, f3 rd) {
+    const float pr = PTK_CAND_REL * (1.0f + fmaxf(fabsf(ro.x), fmaxf(fabsf(ro.y), fabsf(ro.z))));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const f3 inv = mk3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+#else
+    const f3 inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+#endif
+    // plane k of axis a: t = (s[2a+k] - o'.a[k]) * inv.a   (lo planes see the origin moved up by pr, hi planes moved down)
+    const ptk_v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const ptk_v2f ox = {ro.x + pr, ro.x - pr}, oy = {ro.y + pr, ro.y - pr}, oz = {ro.z + pr, ro.z - pr};
+    const float oo = ro.x * ro.x + ro.y * ro.y + ro.z * ro.z;
+    const DevGeomMask m = load_gmask_uniform(S.gmask, base >> 5);
+    const unsigned msph = m.sphere;
+    unsigned hit = 0u;
+    for (int k = 0; k < n; ++k) {
+        const DevGeomBox b = load_gbox_uniform(S.gbox, base + k);
+        ptk_v2f bx = {b.s[0], b.s[1]}, by = {b.s[2], b.s[3]}, bz = {b.s[4], b.s[5]};
+        if ((msph >> k) & 1u) {                          // wave-uniform
+            const float pg = b.qa + b.qb * oo;
+            const ptk_v2f pp = {-pg, pg};
+            bx += pp; by += pp; bz += pp;
+        }
+        const ptk_v2f tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
+        const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+        const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+        hit |= (!(tn > tf) && !(tf <= 0.0f)) ? (1u << k) : 0u;
+    }
+    Cand c; c.cube = hit & m.cube; c.sphere = hit & m.sphere; c.diag = m.diag;
+    return c;
+}
+
+// Closest analytic primitive.  The reference keeps the FIRST primitive in index order among equal distances (strict
+// t_min > t, pathtrace.cu:228).  Staged form: each lane walks its own candidate list, cubes then spheres per chunk of 32
+// primitives (two type-pure loops, max-over-lanes(candidates) trips per wave instead of n_geoms), and the same winner is
+// selected by the order-independent rule "smaller t, or equal t and smaller index".  Unstaged form: the wave-uniform
+// loop over every primitive with the record in SGPRs.
+PTK_DI void analytic_closest(const SceneView& S, const GeomStage& gs, f3 ro, f3 rd, Analytic& a) {
     a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0);
-    float t = -1.f;
-    for (int i = 0; i < S.n_geoms; ++i) {
-        const DevGeom g = load_geom_uniform(S.geoms, i);
-        f3 tp, tn;
-        if (g.type == 1) t = box_test(g, ro, rd, tp, tn);
-        else if (g.type == 0) t = sphere_test(g, ro, rd, tp, tn);
-        if (t > 0.0f && a.t_min > t) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
+    if (!gs.on) {
+        float t = -1.f;
+        for (int i = 0; i < S.n_geoms; ++i) {
+            const DevGeom g = load_geom_uniform(S.geoms, i);
+            f3 tp, tn;
+            if (g.type == 1) t = box_test(g, ro, rd, tp, tn);
+            else if (g.type == 0) t = sphere_test(g, ro, rd, tp, tn);
+            if (t > 0.0f && a.t_min > t) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
+        }
+        return;
+    }
+    for (int base = 0; base < S.n_geoms; base += 32) {
+        const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
+        const Cand c = analytic_candidates(S, base, n, ro, rd);
+        unsigned mc = c.cube, ms = c.sphere;
+        while (mc) {
+            const int k = __builtin_ctz(mc), i = base + k;
+            mc &= mc - 1u;
+            const GeomXf g = load_xf(gs.xf, i, (c.diag >> k) & 1);
+            f3 tp, tn;
+            const float t = box_test(g, ro, rd, tp, tn);
+            if (t > 0.0f && (a.t_min > t || (a.t_min == t && i < a.geom))) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
+        }
+        while (ms) {
+            const int k = __builtin_ctz(ms), i = base + k;
+            ms &= ms - 1u;
+            const GeomXf g = load_xf(gs.xf, i, (c.diag >> k) & 1);
+            f3 tp, tn;
+            const float t = sphere_test(g, ro, rd, tp, tn);
+            if (t > 0.0f && (a.t_min > t || (a.t_min == t && i < a.geom))) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
+        }
     }
 }
 // hit record of an analytic winner (pathtrace.cu:315-340 with the constant normal sampler)
@@ -437,10 +573,9 @@ PTK_DI void triangle_record(const SceneView& S, int tri, float bu, float bv, flo
 }
 
 // computeIntersections body (pathtrace.cu:191-343) for one ray, everything in the calling lane.  Returns rayValid.
+// second half of computeIntersections for one ray: BVH walk seeded with the analytic winner, then the hit record
 template <bool STATS>
-PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
-    Analytic a;
-    analytic_closest(S, ro, rd, a);
+PTK_DI int closest_hit_finish(const SceneView& S, const Analytic& a, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
     int tri = -1; float bu = 0.f, bv = 0.f, t_min = a.t_min;
     if (S.n_tris > 0) {                 // a triangle-free scene has one empty root per direction: it can never hit
         Walk w;
@@ -456,17 +591,48 @@ PTK_DI int closest_hit(const SceneView& S, f3 ro, f3 rd, Hit& h, unsigned& nodeV
     analytic_record(S, a, h);
     return 1;
 }
+template <bool STATS>
+PTK_DI int closest_hit(const SceneView& S, const GeomStage& gs, f3 ro, f3 rd, Hit& h, unsigned& nodeVisits, unsigned& triTests) {
+    Analytic a;
+    analytic_closest(S, gs, ro, rd, a);
+    return closest_hit_finish<STATS>(S, a, ro, rd, h, nodeVisits, triTests);
+}
 
 // LightSampler::occulusionTest, lightSample.h:59-139
-PTK_DI bool occluded(const SceneView& S, f3 ori, f3 dir, f3 des) {
+PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3 des) {
     float minT = length(des - ori);
-    float t = 0.f;
-    for (int i = 0; i < S.n_geoms; ++i) {
-        const DevGeom g = load_geom_uniform(S.geoms, i);
-        f3 tp, tn;
-        if (g.type == 1) t = box_test(g, ori, dir, tp, tn);
-        else if (g.type == 0) t = sphere_test(g, ori, dir, tp, tn);
-        if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
+    if (!gs.on) {
+        float t = 0.f;
+        for (int i = 0; i < S.n_geoms; ++i) {
+            const DevGeom g = load_geom_uniform(S.geoms, i);
+            f3 tp, tn;
+            if (g.type == 1) t = box_test(g, ori, dir, tp, tn);
+            else if (g.type == 0) t = sphere_test(g, ori, dir, tp, tn);
+            if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
+        }
+    } else {
+        // any-hit over the analytic primitives is order-independent, so only the candidates are tested
+        for (int base = 0; base < S.n_geoms; base += 32) {
+            const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
+            const Cand c = analytic_candidates(S, base, n, ori, dir);
+            unsigned mc = c.cube, ms = c.sphere;
+            while (mc) {
+                const int k = __builtin_ctz(mc);
+                mc &= mc - 1u;
+                const GeomXf g = load_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                f3 tp, tn;
+                const float t = box_test(g, ori, dir, tp, tn);
+                if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
+            }
+            while (ms) {
+                const int k = __builtin_ctz(ms);
+                ms &= ms - 1u;
+                const GeomXf g = load_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                f3 tp, tn;
+                const float t = sphere_test(g, ori, dir, tp, tn);
+                if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
+            }
+        }
     }
     if (S.n_tris == 0) return false;
     const DevNode* nodes = S.nodes + (size_t)mtbvh_dir(dir) * S.bvh_size;
@@ -701,7 +867,7 @@ PTK_DI float light_pdf(const SceneView& S, f3 viewPos, f3 lightPos, f3 normal, i
 }
 
 // LightSampler::lightSample, lightSample.h:171-248.  rng is a COPY (by-value parameter in the reference).
-PTK_DI void light_sample(const SceneView& S, const DevMaterial* mats, f3 viewPos, Rng rng, LightRec& rec) {
+PTK_DI void light_sample(const SceneView& S, const GeomStage& gs, const DevMaterial* mats, f3 viewPos, Rng rng, LightRec& rec) {
     rec.pos = mk3(0, 0, 0); rec.emit = mk3(0, 0, 0); rec.pdf = 0.f; rec.is_zero = true;
     int Li = S.n_lights;
     if (Li == 0) return;
@@ -749,7 +915,7 @@ PTK_DI void light_sample(const SceneView& S, const DevMaterial* mats, f3 viewPos
         rec.pdf = 0.f; return;
     }
     f3 rayDir = normalize(lightPos - viewPos);
-    if (occluded(S, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = mk3(0, 0, 0); rec.pdf = -1.f; return; }
+    if (occluded(S, gs, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = mk3(0, 0, 0); rec.pdf = -1.f; return; }
     const DevMaterial& lm = mats[geom.materialid];
     rec.emit = mk3(lm.albedo[0], lm.albedo[1], lm.albedo[2]);
     rec.pdf = pdf; rec.pos = lightPos; rec.is_zero = false;

@@ -12,11 +12,16 @@ struct PtkScene {
 
 namespace ptk {
 
+void set_uniform_analytic(bool on);     // A/B: disable the staged candidate loops (ptk_set_pipeline(2))
+bool uniform_analytic();
+
 // device view of an uploaded scene (pointers into DevScene's buffers), passed to kernels by value
 inline SceneView dev_view(const ::Scene& s) {
     SceneView d;
     const ::DevScene& t = s.tempDevScene;
     d.geoms = (const DevGeom*)t.dev_geoms;       d.n_geoms = (int)s.geoms.size();
+    d.gbox = (const DevGeomBox*)t.dev_gbox;      d.gmask = (const DevGeomMask*)t.dev_gmask;
+    d.lds_geoms = (d.n_geoms > 0 && d.n_geoms <= PTK_LDS_GEOMS_MAX && !uniform_analytic()) ? d.n_geoms : 0;
     d.mats = (const DevMaterial*)t.dev_materials; d.n_mats = (int)s.materials.size();
     d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
     d.trie = (const DevTriE*)t.dev_trie;
@@ -41,6 +46,10 @@ struct Workspace {               // per-render-context scratch, device memory
     int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
     unsigned plane_stride = 0;   // floats per radiance plane (3*P)
     int spp = 1;                 // samples (iterations) per launch
+    // fused bounce kernel (pipeline 3): ticket counter, launch tag and the two scan status tables [blocks]
+    unsigned* ticket = nullptr; unsigned* epoch = nullptr;
+    unsigned long long* st_hit = nullptr; unsigned long long* st_live = nullptr;
+    bool fused = false;
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     int capacity = 0;
 };
@@ -51,7 +60,9 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
                          PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce);
 int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
                                   PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce);
-void set_rays_per_lane(int k);
+int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img,
+                        const Workspace& ws, hipStream_t st, bool last_bounce);
+void set_fused_block(int nt);
 void set_shade_bin(int nt);
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);

@@ -91,7 +91,114 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
     st4(paths.col_pdf, j, make_float4(1.f, 1.f, 1.f, -1.f));
 }
 
+// Closest analytic primitive for every ray of the block, block-cooperatively (all NT threads must call it).
+//
+// The per-lane candidate loops of analytic_closest run max-over-lanes(candidates) exact tests per wave although the MEAN is
+// about half of that (cornell: 1.4 candidates per ray, 2.0 + 1.4 loop trips per wave).  Here the (ray, primitive) candidate
+// pairs of the whole block are written to one LDS list — cube pairs from the front, sphere pairs behind them — and thread j
+// tests pair j, j + NT, ...: every lane of every wave holds a pair, and at most one wave per round mixes the two types.
+// Winner per ray: ds_min_u64 on {t bits : 32 | primitive index : 32} — smaller t, then smaller index, which is the
+// reference's "first in index order among equal distances" (strict t_min > t, pathtrace.cu:228), for any pair order;
+// t > 0 floats order like their bit patterns.  After a barrier the thread whose key is the ray's minimum stores the hit
+// point and the deferred normal for it (a later round can only lower the key, and then overwrites).
+template <int NT>
+__device__ __forceinline__ void analytic_closest_block(const SceneView& S, const GeomStage& gs, bool active, f3 ro, f3 rd, Analytic& a) {
+    constexpr int NW = NT / 64;
+    constexpr int RB = NT == 512 ? 9 : 8;                 // bits of the ray index inside a list entry
+    __shared__ float4 s_ray[2 * NT];                      // origin, direction
+    __shared__ float4 s_res[2 * NT];                      // winner's hit point, deferred normal
+    __shared__ unsigned long long s_best[NT];
+    __shared__ unsigned short s_list[NT * 16];
+    __shared__ int s_cnt[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    s_ray[2 * tid] = make_float4(ro.x, ro.y, ro.z, 0.f);
+    s_ray[2 * tid + 1] = make_float4(rd.x, rd.y, rd.z, 0.f);
+    s_best[tid] = ~0ull;
+    for (int base = 0; base < S.n_geoms; base += 32) {
+        const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
+        const Cand call = analytic_candidates(S, base, n, ro, rd);
+        for (int half = 0; half * 16 < n; ++half) {       // the pair list holds 16 primitives x NT rays
+            Cand c = call;
+            const unsigned hm = 0xffffu << (16 * half);
+            c.cube &= hm; c.sphere &= hm;
+            if (!active) { c.cube = 0u; c.sphere = 0u; }
+            // block-wide exclusive prefix of (cube count | sphere count << 16); a wave total is at most 64 * 16 per half
+            const int v = __popc(c.cube) | (__popc(c.sphere) << 16);
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) s_cnt[wid] = incl;
+            __syncthreads();                              // also publishes s_ray / s_best (first pass) and ends the previous pass's reads
+            int woff_c = 0, woff_s = 0, Tc = 0, Ts = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int cw = s_cnt[w];
+                if (w < wid) { woff_c += cw & 0xffff; woff_s += cw >> 16; }
+                Tc += cw & 0xffff; Ts += cw >> 16;
+            }
+            int oc = woff_c + ((incl - v) & 0xffff), os = Tc + woff_s + ((incl - v) >> 16);
+            for (unsigned m = c.cube; m; m &= m - 1u) s_list[oc++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
+            for (unsigned m = c.sphere; m; m &= m - 1u) s_list[os++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
+            __syncthreads();
+            const int T = Tc + Ts;
+            for (int r0 = 0; r0 < T; r0 += NT) {
+                const int pi = r0 + tid;
+                unsigned long long key = ~0ull;
+                int r = 0;
+                f3 P = mk3(0, 0, 0), NSv = mk3(0, 0, 0);
+                if (pi < T) {
+                    const unsigned e = s_list[pi];
+                    r = (int)(e & ((1u << RB) - 1u));
+                    const int k = (int)(e >> RB);
+                    const float4 o4 = s_ray[2 * r], d4 = s_ray[2 * r + 1];
+                    const GeomXf g = load_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                    const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
+                    const float t = pi < Tc ? box_test(g, po, pd, P, NSv) : sphere_test(g, po, pd, P, NSv);
+                    if (t > 0.0f && FLT_MAX > t) {
+                        key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)(base + k);
+                        atomicMin(&s_best[r], key);
+                    }
+                }
+                __syncthreads();
+                if (key != ~0ull && s_best[r] == key) {
+                    s_res[2 * r] = make_float4(P.x, P.y, P.z, 0.f);
+                    s_res[2 * r + 1] = make_float4(NSv.x, NSv.y, NSv.z, 0.f);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0);
+    const unsigned long long best = s_best[tid];
+    if (best != ~0ull) {
+        const float4 p4 = s_res[2 * tid], n4 = s_res[2 * tid + 1];
+        a.t_min = __uint_as_float((unsigned)(best >> 32)); a.geom = (int)(unsigned)best;
+        a.P = mk3(p4.x, p4.y, p4.z); a.NS = mk3(n4.x, n4.y, n4.z);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
+// Block-cooperative copy of every primitive's inverseTransform / transform rows (dwords [2, 26) of DevGeom) into dynamic
+// LDS; must be reached by all threads of the block.  The launchers size the dynamic LDS with stage_bytes(S).
+extern __shared__ float4 ptk_dyn_lds[];
+__device__ __forceinline__ GeomStage stage_geoms(const SceneView& S) {
+    GeomStage gs;
+    gs.xf = reinterpret_cast<const float*>(ptk_dyn_lds);
+    gs.on = S.lds_geoms > 0;
+    if (gs.on) {
+        float* dst = reinterpret_cast<float*>(ptk_dyn_lds);
+        const float* src = reinterpret_cast<const float*>(S.geoms);
+        const int total = S.n_geoms * PTK_XF_FLOATS;
+        for (int j = threadIdx.x; j < total; j += blockDim.x) {
+            const int g = j / PTK_XF_FLOATS, k = j - g * PTK_XF_FLOATS;
+            dst[j] = src[(size_t)g * (sizeof(DevGeom) / 4) + 2 + k];
+        }
+        __syncthreads();
+    }
+    return gs;
+}
+static inline size_t stage_bytes(const SceneView& S) { return S.lds_geoms > 0 ? (size_t)S.n_geoms * PTK_XF_FLOATS * sizeof(float) : 0; }
+
 // computeIntersections, pathtrace.cu:169-346
 //
 // Triangle-free scenes: k_intersect<*, false> does everything (analytic primitives only; the empty BVH root cannot hit).
@@ -115,7 +222,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
 #define PTK_VALID_TRI 2          // flag value between k_traverse and k_finalize: "closest hit is a triangle, record pending"
 
 template <bool STATS, bool SPLIT>
-__global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
+__global__ void __launch_bounds__(PTK_BLOCK, 5) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
                                                           unsigned long long* ray_total, unsigned long long* stats,
                                                           int* __restrict__ heavy_flag, int* __restrict__ heavy_agg) {
@@ -124,16 +231,22 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     if (i == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
+    const GeomStage gs = stage_geoms(S);
     int flag = 0;
     bool heavy = false;
     unsigned nv = 0, nt = 0;
-    if (i < n) {
+    const bool active = i < n;
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+    if (active) {
         const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i);
-        const f3 ro = mk3(o4.x, o4.y, o4.z), rd = mk3(d4.x, d4.y, d4.z);
+        ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+    }
+    Analytic a;
+    if (gs.on) analytic_closest_block<PTK_BLOCK>(S, gs, active, ro, rd, a);          // block-cooperative: every thread takes part
+    else if (active) analytic_closest(S, gs, ro, rd, a);
+    if (active) {
         Hit h;
         if (SPLIT) {
-            Analytic a;
-            analytic_closest(S, ro, rd, a);
             flag = a.geom >= 0;
             if (flag) analytic_record(S, a, h);
             // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
@@ -142,7 +255,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
             heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
             if (STATS && !heavy) nv = 1;
         } else {
-            flag = closest_hit<STATS>(S, ro, rd, h, nv, nt);
+            flag = closest_hit_finish<STATS>(S, a, ro, rd, h, nv, nt);
         }
         if (flag) {
             st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
@@ -163,95 +276,6 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
         int total;
         (void)block_excl_prefix(flag, total);
         if (threadIdx.x == 0) agg[b] = total;
-    }
-    if (STATS && stats) {
-        unsigned long long a = nv, c = nt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
-    }
-}
-
-// Two rays per lane (ILP-2 form of the one-kernel layout; pipeline 2, measured SLOWER than one ray per lane on MI355X:
-// bunny scene 1.54 vs 1.17 ms of intersect time per iteration, cornell 0.29 vs 0.26 — kept for A/B runs only).  Thread t of block b owns paths b*512 + t and b*512 + 256 + t, so
-// every wave access stays coalesced and the flag aggregates still cover 256-path ranges (agg[2b], agg[2b+1]).
-// Why: (1) the threaded-BVH walk is a chain of dependent 32-B loads and, once the cheap rays have retired, only 2-3 waves
-// per SIMD are left to hide their latency; walking two independent rays per lane issues both node loads before either test,
-// halving the exposed latency per visit; (2) each SGPR-resident primitive record is used for two rays per scalar load.
-template <bool STATS>
-__global__ void __launch_bounds__(PTK_BLOCK) k_intersect2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
-                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
-                                                           unsigned long long* ray_total, unsigned long long* stats) {
-    const int n = d_n ? *d_n : n_arg;
-    const int b = blockIdx.x;
-    if (b * (2 * PTK_BLOCK) >= n) return;
-    const int i0 = b * (2 * PTK_BLOCK) + threadIdx.x, i1 = i0 + PTK_BLOCK;
-    if (i0 == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
-    const bool on0 = i0 < n, on1 = i1 < n;
-    const float4 o40 = on0 ? ld4(paths.o_pix, i0) : make_float4(0, 0, 0, 0), d40 = on0 ? ld4(paths.d_bnc, i0) : make_float4(1, 0, 0, 0);
-    const float4 o41 = on1 ? ld4(paths.o_pix, i1) : make_float4(0, 0, 0, 0), d41 = on1 ? ld4(paths.d_bnc, i1) : make_float4(1, 0, 0, 0);
-    const f3 ro0 = mk3(o40.x, o40.y, o40.z), rd0 = mk3(d40.x, d40.y, d40.z);
-    const f3 ro1 = mk3(o41.x, o41.y, o41.z), rd1 = mk3(d41.x, d41.y, d41.z);
-    Analytic a0, a1;
-    a0.t_min = a1.t_min = FLT_MAX; a0.geom = a1.geom = -1;
-    a0.P = a1.P = a0.NS = a1.NS = mk3(0, 0, 0);
-    {
-        float t0 = -1.f, t1 = -1.f;
-        for (int i = 0; i < S.n_geoms; ++i) {                    // one scalar load of the primitive, two rays tested
-            const DevGeom g = load_geom_uniform(S.geoms, i);
-            f3 p0, s0, p1, s1;
-            if (g.type == 1) { t0 = box_test(g, ro0, rd0, p0, s0); t1 = box_test(g, ro1, rd1, p1, s1); }
-            else if (g.type == 0) { t0 = sphere_test(g, ro0, rd0, p0, s0); t1 = sphere_test(g, ro1, rd1, p1, s1); }
-            if (t0 > 0.0f && a0.t_min > t0) { a0.t_min = t0; a0.geom = i; a0.P = p0; a0.NS = s0; }
-            if (t1 > 0.0f && a1.t_min > t1) { a1.t_min = t1; a1.geom = i; a1.P = p1; a1.NS = s1; }
-        }
-    }
-    unsigned nv = 0, nt = 0;
-    int tri0 = -1, tri1 = -1; float u0 = 0, v0 = 0, u1 = 0, v1 = 0, tm0 = a0.t_min, tm1 = a1.t_min;
-    if (S.n_tris > 0) {
-        Walk w0, w1;
-        walk_begin(S, ro0, rd0, a0.t_min, w0);
-        walk_begin(S, ro1, rd1, a1.t_min, w1);
-        if (!on0) w0.idx = -1;
-        if (!on1) w1.idx = -1;
-        while (w0.idx != -1 || w1.idx != -1) {
-            const bool act0 = w0.idx != -1, act1 = w1.idx != -1;
-            const DevNode n0 = w0.nodes[act0 ? w0.idx : 0];      // both loads are issued before either test
-            const DevNode n1 = w1.nodes[act1 ? w1.idx : 0];
-            if (act0) { const int k = walk_apply(S, w0, n0); if (STATS) { nv++; nt += k; } }
-            if (act1) { const int k = walk_apply(S, w1, n1); if (STATS) { nv++; nt += k; } }
-        }
-        tri0 = w0.tri; u0 = w0.u; v0 = w0.v; tm0 = w0.t_min;
-        tri1 = w1.tri; u1 = w1.u; v1 = w1.v; tm1 = w1.t_min;
-    } else if (STATS) nv += (on0 ? 1 : 0) + (on1 ? 1 : 0);
-    int f0 = 0, f1 = 0;
-    if (on0) {
-        Hit h;
-        if (tri0 >= 0) { triangle_record(S, tri0, u0, v0, tm0, h); f0 = 1; }
-        else if (a0.geom >= 0) { analytic_record(S, a0, h); f0 = 1; }
-        if (f0) {
-            st4(hits.t_n, i0, make_float4(h.t, h.n.x, h.n.y, h.n.z));
-            st4(hits.p_mat, i0, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
-            st4(hits.uv_ids, i0, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
-        } else st4(hits.t_n, i0, make_float4(-1.f, 0.f, 0.f, 0.f));
-        valid[i0] = f0;
-    }
-    if (on1) {
-        Hit h;
-        if (tri1 >= 0) { triangle_record(S, tri1, u1, v1, tm1, h); f1 = 1; }
-        else if (a1.geom >= 0) { analytic_record(S, a1, h); f1 = 1; }
-        if (f1) {
-            st4(hits.t_n, i1, make_float4(h.t, h.n.x, h.n.y, h.n.z));
-            st4(hits.p_mat, i1, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
-            st4(hits.uv_ids, i1, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
-        } else st4(hits.t_n, i1, make_float4(-1.f, 0.f, 0.f, 0.f));
-        valid[i1] = f1;
-    }
-    if (agg) {
-        int tot0, tot1;
-        (void)block_excl_prefix(f0, tot0);
-        (void)block_excl_prefix(f1, tot1);
-        if (threadIdx.x == 0) { agg[2 * b] = tot0; agg[2 * b + 1] = tot1; }
     }
     if (STATS && stats) {
         unsigned long long a = nv, c = nt;
@@ -362,7 +386,7 @@ __device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
 }
 
 template <int MODE>
-__device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
+__device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& gs, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
     if (h.t <= 0.f) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
     const MatEval m = eval_material(S, S.mats[h.mat], h.uv);
     Rng rng = make_rng(iter, slot, depth);
@@ -374,7 +398,7 @@ __device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot
             return 0;
         }
         LightRec li;
-        light_sample(S, S.mats, h.p, rng, li);
+        light_sample(S, gs, S.mats, h.p, rng, li);
         if (li.pdf <= 0) { p.col = p.col * 0.f; return 0; }
         const f3 wi = normalize(li.pos - h.p);
         const f3 f = mat_bsdf(m, h.n, p.d, wi);
@@ -400,7 +424,7 @@ __device__ __forceinline__ int shade_path(const SceneView& S, int iter, int slot
     const bool isDelta = (m.type == PTK_MAT_DIELECTRIC);
     if (MODE == PTK_MODE_MIS && !isDelta) {
         LightRec li;
-        light_sample(S, S.mats, h.p, rng, li);                        // rng by value: the path's stream does not advance
+        light_sample(S, gs, S.mats, h.p, rng, li);                        // rng by value: the path's stream does not advance
         if (!li.is_zero) {
             const f3 wi = normalize(li.pos - h.p);
             const float bp = mat_pdf(m, h.n, p.d, wi);
@@ -432,6 +456,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
     const Film img = {img_base, plane_stride};
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
+    GeomStage gs; gs.xf = nullptr; gs.on = false;
+    if (MODE != PTK_MODE_BSDF) gs = stage_geoms(S);          // only the light-sampling modes trace shadow rays
     const int i = b * PTK_BLOCK + threadIdx.x;
     int flag = (i < n) ? 1 : 0;
     int slot = i;
@@ -452,7 +478,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
         p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-        alive = shade_path<MODE>(S, iter, slot, depth, h, p, img);
+        alive = shade_path<MODE>(S, gs, iter, slot, depth, h, p, img);
         st4(paths.o_pix, i, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
         st4(paths.d_bnc, i, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
         st4(paths.col_pdf, i, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
@@ -486,6 +512,8 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
     const Film img = {img_base, plane_stride};
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (b * NT >= n) return;
+    GeomStage gs; gs.xf = nullptr; gs.on = false;
+    if (MODE != PTK_MODE_BSDF) gs = stage_geoms(S);
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // --- original order: flag, compacted slot, material key
@@ -535,7 +563,7 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
         p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-        alive = shade_path<MODE>(S, iter, slot, depth, h, p, img);
+        alive = shade_path<MODE>(S, gs, iter, slot, depth, h, p, img);
         st4(paths.o_pix, it, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
         st4(paths.d_bnc, it, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
         st4(paths.col_pdf, it, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
@@ -594,6 +622,182 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_scatter(int n_arg, const int* __r
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Fused bounce (pipeline 3): computeIntersections + compact + shade + compact of pathtrace.cu:700-790 in ONE launch.
+//
+// Each path stays in registers from its ray to its scattered successor: the hit record is never written, and the two
+// order-preserving compactions of the reference become two single-pass chained scans ("decoupled look-back") over the
+// blocks of the launch:
+//   scan 1 (hits)      gives every hit path its compacted slot == the reference's RNG key for the shading kernels;
+//   scan 2 (survivors) gives every surviving path its position in the next bounce's stream (stable, like thrust).
+// HBM traffic per path-bounce: 48 B in + 48 B out for survivors (+ the radiance read-modify-write), instead of the staged
+// layout's 76 + 152 + ~100 B, and one launch per bounce instead of three.
+//
+// Scan protocol (inter-workgroup, MI355X_MICROARCH "inter-workgroup visibility"): one 8-byte granule per block and scan,
+// {tag:32 | kind:2 | value:30}, written by ONE agent-scope relaxed store (sc1) and polled with agent-scope relaxed loads by
+// wave 0 of the waiting block; the payload is inside the granule, so no fence is needed.  kind 1 = this block's aggregate,
+// kind 2 = inclusive prefix.  `tag` is a per-launch number from a device counter, so the tables never need clearing.
+// Logical block ids come from a ticket counter (not blockIdx), so a block can only ever wait for blocks that are already
+// running — progress does not depend on dispatch order or on what other streams' kernels occupy the CUs.  Blocks beyond
+// the live count exit before drawing a ticket.  The block that draws the last ticket resets the ticket, steps the tag
+// and (last bounce) the device-resident iteration number: every participating block has read those words by then,
+// because thread 0 reads them BEFORE drawing its ticket and hands them to the block through LDS.
+// ------------------------------------------------------------------------------------------------------------------
+#define PTK_SCAN_AGG 1u
+#define PTK_SCAN_PREFIX 2u
+__device__ __forceinline__ unsigned long long scan_pack(unsigned tag, unsigned kind, int value) {
+    return ((unsigned long long)tag << 32) | ((unsigned long long)kind << 30) | (unsigned)value;
+}
+
+// exclusive prefix over the logical blocks before `b` of the per-block totals; publishes this block's own status.
+// Called by every thread of the block (contains barriers).  Values are < 2^30.
+template <int NT>
+__device__ __forceinline__ int lookback_exclusive(unsigned long long* __restrict__ st, unsigned tag, int b, int total) {
+    __shared__ int s_excl;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&st[b], scan_pack(tag, b == 0 ? PTK_SCAN_PREFIX : PTK_SCAN_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0;
+        if (b > 0) {
+            int pos = b - 1;                                   // lane 0 examines the nearest predecessor
+            for (;;) {
+                const int idx = pos - lane;
+                unsigned long long w = scan_pack(tag, PTK_SCAN_PREFIX, 0);      // "before block 0": prefix 0
+                bool ready = idx < 0;
+                for (;;) {
+                    if (!ready) {
+                        w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = (unsigned)(w >> 32) == tag;
+                    }
+                    if (__ballot(!ready) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned kind = (unsigned)(w >> 30) & 3u;
+                const unsigned long long pm = __ballot(kind == PTK_SCAN_PREFIX);
+                const int first = pm ? (int)__builtin_ctzll(pm) : 63;          // nearest predecessor holding an inclusive prefix
+                int v = (lane <= first) ? (int)((unsigned)w & 0x3FFFFFFFu) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                excl += v;
+                if (pm) break;
+                pos -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&st[b], scan_pack(tag, PTK_SCAN_PREFIX, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const int r = s_excl;
+    __syncthreads();
+    return r;
+}
+
+template <int NT>
+__device__ __forceinline__ int block_excl_prefix_n(int flag, int& total) {
+    constexpr int NW = NT / 64;
+    __shared__ int wsum[NW];
+    const unsigned long long bal = __ballot(flag != 0);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wid] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int c = wsum[w]; off += (w < wid) ? c : 0; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + within;
+}
+
+struct FusedArgs {
+    int iter_arg; const int* iter_ptr; int depth;
+    int n_arg; const int* d_n;
+    PtkPaths cur, nxt;
+    float* img; unsigned plane_stride; int spp;
+    int* count_out;                          // live paths entering the next bounce
+    unsigned long long* ray_total;
+    unsigned long long* stats;
+    unsigned* ticket; unsigned* epoch;       // LookBack state of this lane (ptk_internal.h)
+    unsigned long long* st_hit; unsigned long long* st_live;
+    int* iter_advance; int iter_stride;      // last bounce of an iteration: step the device-resident iteration number
+};
+
+template <int MODE, bool STATS, int NT>
+__global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
+    __shared__ int s_hdr[4];                 // ticket, tag, n, step
+    if (threadIdx.x == 0) {
+        const int n0 = A.d_n ? *A.d_n : A.n_arg;
+        const int step0 = A.iter_ptr ? *A.iter_ptr : A.iter_arg;
+        const unsigned tag0 = __hip_atomic_load(A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ticket = -1;
+        const int nb = n0 > 0 ? (n0 + NT - 1) / NT : 0;
+        if ((int)blockIdx.x < nb || (nb == 0 && blockIdx.x == 0)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // n, step, tag are in registers before the ticket is drawn
+            if (nb > 0) ticket = (int)atomicAdd(A.ticket, 1u);
+            if (nb == 0 || ticket == nb - 1) {                               // every participating block holds its ticket and has read the words above
+                __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.epoch, tag0 + 1u == 0u ? 1u : tag0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (A.iter_advance) *A.iter_advance += A.iter_stride;
+                if (A.ray_total && n0 > 0) atomicAdd(A.ray_total, (unsigned long long)n0);
+                if (nb == 0 && A.count_out) *A.count_out = 0;
+            }
+        }
+        s_hdr[0] = ticket; s_hdr[1] = (int)tag0; s_hdr[2] = n0; s_hdr[3] = step0;
+    }
+    __syncthreads();
+    const int b = s_hdr[0];
+    const unsigned tag = (unsigned)s_hdr[1];
+    const int n = s_hdr[2];
+    const int iter = (s_hdr[3] - 1) * A.spp + 1;
+    if (b < 0) return;
+    const GeomStage gs = stage_geoms(S);
+    const Film img = {A.img, A.plane_stride};
+    const int i = b * NT + threadIdx.x;
+    // ---- phase A: closest hit (computeIntersections) -------------------------------------------------------------
+    int flag = 0;
+    unsigned nv = 0, nt = 0;
+    Hit h;
+    PathRegs p;
+    h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
+    p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
+    if (i < n) {
+        const float4 o4 = ld4(A.cur.o_pix, i), d4 = ld4(A.cur.d_bnc, i);
+        p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+        p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+        flag = closest_hit<STATS>(S, gs, p.o, p.d, h, nv, nt);
+        if (!flag && S.env_tex >= 0) {                                  // environment map on a miss (pathtrace.cu:303-311)
+            const float4 c4 = ld4(A.cur.col_pdf, i);
+            add_radiance(img, p.pix, nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, p.d)));
+        }
+    }
+    int total;
+    const int local = block_excl_prefix_n<NT>(flag, total);
+    const int prior = lookback_exclusive<NT>(A.st_hit, tag, b, total);
+    // ---- phase B: shade the hits, keyed by their compacted slot ----------------------------------------------------
+    int alive = 0;
+    if (flag) {
+        const float4 c4 = ld4(A.cur.col_pdf, i);
+        p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+        alive = shade_path<MODE>(S, gs, iter, prior + local, A.depth, h, p, img);
+    }
+    int total2;
+    const int local2 = block_excl_prefix_n<NT>(alive, total2);
+    const int prior2 = lookback_exclusive<NT>(A.st_live, tag, b, total2);
+    if (alive) {
+        const int s = prior2 + local2;
+        st4(A.nxt.o_pix, s, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+        st4(A.nxt.d_bnc, s, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+        st4(A.nxt.col_pdf, s, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+    }
+    if (A.count_out && threadIdx.x == 0 && b == (n - 1) / NT) *A.count_out = prior2 + total2;
+    if (STATS && A.stats) {
+        unsigned long long a = nv, c = nt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&A.stats[0], a); atomicAdd(&A.stats[1], c); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // sendImageToPBO, pathtrace.cu:32-65 (ACESFilm + gammaCorrection, utilities.h:35-48)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PTK_BLOCK) k_tonemap(const float* __restrict__ img, int P, int iter, uchar4* __restrict__ pbo) {
@@ -643,8 +847,8 @@ int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_
     if (g == 0) return 0;
     switch (mode) {
     case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -660,17 +864,33 @@ int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, in
     if (g == 0) return 0;
     switch (mode) {
     case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
 }
 
-int g_rays_per_lane = 1;               // 1: k_intersect (default), 2: k_intersect2 (two rays per lane; measured slower)
 unsigned* g_abi_queue = nullptr;       // traversal list counter + list for the kernel-level ptk_intersect entry point
 int* g_abi_list = nullptr;
 int g_abi_list_cap = 0;
+int g_fused_block = 256;               // threads per block of k_bounce (256 or 512)
+
+template <int MODE, int NT>
+int launch_fused_nt(const SceneView& S, const FusedArgs& A, int capacity, bool stats, hipStream_t st) {
+    const int g = (capacity + NT - 1) / NT;
+    if (g == 0) return 0;
+    if (stats) k_bounce<MODE, true, NT><<<g, NT, stage_bytes(S), st>>>(S, A);
+    else k_bounce<MODE, false, NT><<<g, NT, stage_bytes(S), st>>>(S, A);
+    return launch_rc();
+}
+template <int MODE>
+int launch_fused_mode(const SceneView& S, const FusedArgs& A, int capacity, bool stats, hipStream_t st) {
+    if (g_fused_block == 512) return launch_fused_nt<MODE, 512>(S, A, capacity, stats, st);
+    return launch_fused_nt<MODE, 256>(S, A, capacity, stats, st);
+}
+
+bool g_uniform_analytic = false;       // A/B switch: wave-uniform loops over every analytic primitive (no LDS staging, no candidate test)
 
 // scratch for the stand-alone ptk_compact entry point (per-block aggregates), grown on demand
 int* g_compact_agg = nullptr;
@@ -713,21 +933,14 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
     mark(1, true);
-    if (!split && g_rays_per_lane == 2) {
-        const int g2 = (n + 2 * PTK_BLOCK - 1) / (2 * PTK_BLOCK);
-        if (stats) k_intersect2<true><<<g2, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats);
-        else k_intersect2<false><<<g2, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr);
-        mark(1, false);
-        return launch_rc();
-    }
     if (!split) {
-        if (stats) k_intersect<true, false><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats, nullptr, nullptr);
-        else k_intersect<false, false><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr, nullptr, nullptr);
+        if (stats) k_intersect<true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats, nullptr, nullptr);
+        else k_intersect<false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr, nullptr, nullptr);
         mark(1, false);
         return launch_rc();
     }
-    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg);
-    else k_intersect<false, true><<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg);
+    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg);
+    else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
@@ -770,7 +983,29 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
                          PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce) {
     return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark, last_bounce);
 }
-void set_rays_per_lane(int k) { g_rays_per_lane = (k == 2) ? 2 : 1; }
+// one bounce of the fused pipeline (k_bounce): a single launch
+int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img,
+                        const Workspace& ws, hipStream_t st, bool last_bounce) {
+    if (!ws.ticket || !ws.epoch || !ws.st_hit || !ws.st_live) return PTK_E_BADARG;
+    FusedArgs A;
+    A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth = depth;
+    A.n_arg = capacity; A.d_n = ws.counts + depth;
+    A.cur = cur; A.nxt = nxt;
+    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp;
+    A.count_out = ws.counts + depth + 1;
+    A.ray_total = ws.ray_total; A.stats = ws.stats;
+    A.ticket = ws.ticket; A.epoch = ws.epoch; A.st_hit = ws.st_hit; A.st_live = ws.st_live;
+    A.iter_advance = last_bounce ? ws.iter_dev : nullptr; A.iter_stride = ws.iter_stride;
+    switch (mode) {
+    case PTK_MODE_BSDF: return launch_fused_mode<PTK_MODE_BSDF>(S, A, capacity, ws.stats != nullptr, st);
+    case PTK_MODE_DIRECTLI: return launch_fused_mode<PTK_MODE_DIRECTLI>(S, A, capacity, ws.stats != nullptr, st);
+    case PTK_MODE_MIS: return launch_fused_mode<PTK_MODE_MIS>(S, A, capacity, ws.stats != nullptr, st);
+    default: return PTK_E_BADARG;
+    }
+}
+void set_fused_block(int nt) { g_fused_block = (nt == 512) ? 512 : 256; }
+void set_uniform_analytic(bool on) { g_uniform_analytic = on; }
+bool uniform_analytic() { return g_uniform_analytic; }
 void set_shade_bin(int nt) { g_shade_bin = (nt == 256 || nt == 512 || nt == 1024) ? nt : 0; }
 
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st) {

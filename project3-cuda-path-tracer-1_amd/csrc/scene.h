@@ -101,6 +101,8 @@ public:
     void destroy();
     int tri_num = 0, bvh_size = 0;
     void* dev_geoms = nullptr;        // ptk::DevGeom[]
+    void* dev_gbox = nullptr;         // ptk::DevGeomBox[]
+    void* dev_gmask = nullptr;        // ptk::DevGeomMask[]
     void* dev_materials = nullptr;    // ptk::DevMaterial[]
     void* dev_nodes = nullptr;        // ptk::DevNode[6][bvh_size]
     void* dev_trie = nullptr;         // ptk::DevTriE[]

@@ -51,6 +51,8 @@ L.orc_rng_uniforms_seed.argtypes = [C.c_uint32, ci, vp]
 L.orc_ptk_sincos_array.argtypes = [vp, ci, vp, vp]
 L.orc_box_test.restype = C.c_float; L.orc_box_test.argtypes = [vp, vp, vp, vp, vp]
 L.orc_sphere_test.restype = C.c_float; L.orc_sphere_test.argtypes = [vp, vp, vp, vp, vp]
+L.orc_box_test_array.argtypes = [vp, vp, vp, ci, vp]
+L.orc_sphere_test_array.argtypes = [vp, vp, vp, ci, vp]
 L.orc_aabb_test.argtypes = [vp, vp, vp, vp, vp]
 L.orc_tri_test.argtypes = [vp, vp, vp, vp]
 L.orc_make_geom.argtypes = [ci, ci, vp, vp, vp, vp]

@@ -173,10 +173,11 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
-@pytest.mark.parametrize("pipeline", [1, 2])
+@pytest.mark.parametrize("pipeline", [1, 2, 3])
 def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
-    """ptk_set_pipeline variants (1 = BVH walked inside the intersect kernel, 2 = the same with two rays per lane; the default 0
-    is the work-list layout exercised by every other test) produce exactly the oracle's results."""
+    """ptk_set_pipeline variants (1 = staged kernels with the BVH walked inside the intersect kernel, 2 = the same with wave-uniform
+    loops over every analytic primitive instead of the staged candidate loops, 3 = the fused bounce kernel with chained scans)
+    produce exactly the oracle's results."""
     for name, res, depth, mode in (("bunny_cornell.txt", (128, 128), 5, "MIS"), ("obj_test.txt", (64, 64), 4, "BSDF"), ("cornell.txt", (96, 96), 4, "BSDF")):
         m = MODES[mode]
         s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
@@ -439,3 +440,64 @@ def test_full_size_properties_2048(ptk, torch_cuda):
     assert c1[0] == 2048 * 2048 and (np.diff(c1) <= 0).all()
     # additivity: image after iterations {1,2} == image(1) + image(2) (same float additions per pixel, in order)
     assert np.array_equal(ab, a + b)
+
+
+def _many_primitives_scene(path, n_geoms, seed):
+    """Synthetic scene: a lit room plus `n_geoms` random cubes / spheres, most of them rotated (non-diagonal transforms), many
+    overlapping or touching, a few far away and a few huge — the stress case of the conservative candidate test (chunks of 32
+    primitives, per-lane candidate lists, the equal-distance tie rule)."""
+    rng = np.random.default_rng(seed)
+    L = ["MATERIAL light", "TYPE Light", "ALBEDO 6 6 6", "",
+         "MATERIAL white", "TYPE Lambertian", "ALBEDO 0.8 0.8 0.8", "",
+         "MATERIAL red", "TYPE Lambertian", "ALBEDO 0.8 0.2 0.2", "",
+         "MATERIAL glass", "TYPE Dielectric", "ALBEDO 0.95 0.95 0.95", "IOR 1.5", "",
+         "MATERIAL metal", "TYPE MetallicWorkflow", "ALBEDO 0.9 0.7 0.3", "ROUGHNESS 0.3", "METALLIC 0.8", "",
+         "CAMERA", "RES 96 96", "FOVY 22", "ITERATIONS 4", "DEPTH 6", "FILE many", "EYE 0 5 14", "LOOKAT 0 5 0", "UP 0 1 0", ""]
+    objs = [("sphere", "light", (0, 9, 0), (0, 0, 0), (2, 2, 2)), ("sphere", "light", (-3, 2, 2), (0, 0, 0), (1, 1, 1)),
+            ("cube", "white", (0, 0, 0), (0, 0, 0), (12, 0.02, 12)), ("cube", "white", (0, 10, 0), (0, 0, 0), (12, 0.02, 12)),
+            ("cube", "red", (-6, 5, 0), (0, 0, 0), (0.02, 10, 12)), ("cube", "white", (6, 5, 0), (0, 0, 0), (0.02, 10, 12)),
+            ("cube", "white", (0, 5, -6), (0, 0, 0), (12, 10, 0.02)),
+            ("cube", "metal", (0, 5, 0), (0, 45, 0), (1e3, 0.01, 1e-2)),            # a very long thin beam
+            ("sphere", "glass", (400, 5, 0), (0, 0, 0), (3, 3, 3))]                # far outside the room
+    mats = ["white", "red", "glass", "metal"]
+    while len(objs) < n_geoms:
+        kind = "cube" if rng.random() < 0.6 else "sphere"
+        pos = rng.uniform([-5, 0.5, -5], [5, 9, 4])
+        rot = rng.uniform(-180, 180, 3) if rng.random() < 0.8 else np.zeros(3)
+        sc = rng.uniform(0.2, 1.6, 3) if kind == "cube" else np.repeat(rng.uniform(0.3, 1.5), 3)
+        if rng.random() < 0.15 and len(objs) > 10:             # duplicate an earlier primitive exactly: equal distances
+            k, _, pos, rot, sc = objs[int(rng.integers(9, len(objs)))]
+            kind = k
+        objs.append((kind, mats[int(rng.integers(0, 4))], tuple(pos), tuple(rot), tuple(sc)))
+    for i, (kind, mat, pos, rot, sc) in enumerate(objs):
+        L += [f"OBJECT o{i}", kind, f"material {mat}", "TRANS %.6g %.6g %.6g" % tuple(pos), "ROTAT %.6g %.6g %.6g" % tuple(rot),
+              "SCALE %.6g %.6g %.6g" % tuple(sc), ""]
+    with open(path, "w") as f:
+        f.write("\n".join(L) + "\n")
+
+
+@pytest.mark.parametrize("n_geoms,mode", [(70, "MIS"), (33, "BSDF"), (140, "DIRECT")])
+def test_many_primitives(ptk, orc, torch_cuda, tmp_path, n_geoms, mode):
+    """More analytic primitives than one 32-wide candidate chunk, rotated and overlapping: images and live counts == oracle,
+    for the staged candidate loops (default) and for the wave-uniform loops (pipeline 2)."""
+    path = str(tmp_path / "many.txt")
+    _many_primitives_scene(path, n_geoms, seed=n_geoms)
+    m = MODES[mode]
+    o = orc.Scene(path)
+    ref = np.zeros((o.P, 3), np.float32)
+    lives = []
+    for it in (1, 2, 3):
+        _, live = o.pathtrace(m, it, ref)
+        lives.append(live)
+    assert ref.sum() > 0
+    for pipeline in (0, 2):
+        s = ptk.Scene(path)
+        assert s.n_geoms == n_geoms
+        r = ptk.Renderer(s, m, pipeline=pipeline)
+        for k, it in enumerate((1, 2, 3)):
+            r.iterate(it)
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, lives[k]), (pipeline, it)
+        img = r.image(); r.close()
+        bad = (img != ref).any(axis=1)
+        assert not bad.any(), f"pipeline {pipeline}: {int(bad.sum())} of {len(ref)} pixels differ"
