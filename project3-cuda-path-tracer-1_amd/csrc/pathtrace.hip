@@ -85,6 +85,7 @@ int context_free() {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
+        dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first);
         dfree(l.ws.ticket); dfree(l.ws.epoch); dfree(l.ws.st_hit); dfree(l.ws.st_live);
         dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
@@ -124,6 +125,9 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.queue, 1))) return rc;
     if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
+    if ((rc = dalloc(&l.ws.srcidx, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.seg_pref, blocks + 16))) return rc;
+    if ((rc = dalloc(&l.ws.seg_first, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.ticket, 1))) return rc;
     if ((rc = dalloc(&l.ws.epoch, 1))) return rc;
     if ((rc = dalloc(&l.ws.st_hit, blocks))) return rc;
@@ -139,8 +143,9 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
-    l.ws.inline_bvh = (g.pipeline != 0);
+    l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline != 4);
     l.ws.fused = (g.pipeline == 3);
+    l.ws.segmented = (g.pipeline != 4);
     l.ws.capacity = g.capacity;
     l.last_iter = 0;
     return 0;
@@ -388,9 +393,9 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     return x + y * W;
 }
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 3) return PTK_E_BADARG;
+    if (which < 0 || which > 4) return PTK_E_BADARG;
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0); l.ws.fused = (which == 3); }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which != 4); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); }
     set_uniform_analytic(which == 2);
     return 0;
 }

@@ -157,6 +157,8 @@ struct SceneView {
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;
     const DevTex* tex;           const float* texels;   int env_tex;     // env_tex = envMapID (-1: none)
+    int n_tex;                   // number of textures
+    int slim_hits;               // render pipeline only: 1 = the (uv, geomID, triangleID) third of the hit record is unused
 };
 
 // Wave-uniform load of one primitive record into SGPRs.  The scene tables are immutable while a kernel runs, but the

@@ -28,6 +28,7 @@ inline SceneView dev_view(const ::Scene& s) {
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
     d.tex = (const DevTex*)t.dev_textures;       d.texels = (const float*)t.dev_texture_data; d.env_tex = t.envMapID;
+    d.n_tex = t.tex_num; d.slim_hits = 0;
     return d;
 }
 
@@ -49,7 +50,10 @@ struct Workspace {               // per-render-context scratch, device memory
     // fused bounce kernel (pipeline 3): ticket counter, launch tag and the two scan status tables [blocks]
     unsigned* ticket = nullptr; unsigned* epoch = nullptr;
     unsigned long long* st_hit = nullptr; unsigned long long* st_live = nullptr;
-    bool fused = false;
+    bool fused = false;          // pipeline 3
+    // segmented path streams (default): physical slot of every dense path, window prefix and first-window tables
+    int* srcidx = nullptr; int* seg_pref = nullptr; int* seg_first = nullptr;
+    bool segmented = true;       // false: k_scatter moves the survivors (pipeline 4)
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     int capacity = 0;
 };

@@ -177,6 +177,31 @@ __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const
     }
 }
 
+// Segmented path streams (default render pipeline).  The shading kernel writes the survivors of its block contiguously at
+// the START of the block's own 256-slot window of the next buffer ("block-local compaction", no global scan needed), and
+// k_segments turns the per-block counts into seg_pref (exclusive prefix) and seg_first (for every 256-path range of the
+// dense order, the window that holds its first path).  The next bounce's kernels address paths by DENSE index — the
+// reference's compacted order, still the RNG key — and find the physical slot here.  Compared with moving every live
+// path once more (k_scatter: 52 B read + 48 B written per path and bounce) this costs five scalar loads per block.
+struct Gather {
+    const int* pref;      // [windows + 8]: dense index of the first path of window w; entries past the last window = total.  nullptr: dense stream
+    const int* first;     // [dense 256-ranges]: window containing dense index 256 * B
+    int* src;             // out: physical index of every dense path (read by the kernels that follow the intersect kernel)
+};
+__device__ __forceinline__ int gather_source(const Gather& G, int b, int i, int n) {
+    if (!G.pref) return i;
+    const int w0 = G.first[b];                                    // block-uniform: scalar loads
+    const int p0 = G.pref[w0], p1 = G.pref[w0 + 1], p2 = G.pref[w0 + 2], p3 = G.pref[w0 + 3], p4 = G.pref[w0 + 4];
+    if (i >= n) return 0;
+    int k = (i >= p1) + (i >= p2) + (i >= p3) + (i >= p4);
+    int base = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : (k == 3 ? p3 : p4)));
+    if (k == 4) {                                                 // many sparse windows in a row: walk on (pref ends with `total` > i)
+        int nxt = G.pref[w0 + k + 1];
+        while (i >= nxt) { base = nxt; ++k; nxt = G.pref[w0 + k + 1]; }
+    }
+    return (w0 + k) * PTK_BLOCK + (i - base);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Block-cooperative copy of every primitive's inverseTransform / transform rows (dwords [2, 26) of DevGeom) into dynamic
 // LDS; must be reached by all threads of the block.  The launchers size the dynamic LDS with stage_bytes(S).
@@ -225,12 +250,13 @@ template <bool STATS, bool SPLIT>
 __global__ void __launch_bounds__(PTK_BLOCK, 5) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
                                                           unsigned long long* ray_total, unsigned long long* stats,
-                                                          int* __restrict__ heavy_flag, int* __restrict__ heavy_agg) {
+                                                          int* __restrict__ heavy_flag, int* __restrict__ heavy_agg, Gather G) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     if (i == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
+    const int src = gather_source(G, b, i, n);
     const GeomStage gs = stage_geoms(S);
     int flag = 0;
     bool heavy = false;
@@ -238,8 +264,9 @@ __global__ void __launch_bounds__(PTK_BLOCK, 5) k_intersect(SceneView S, int n_a
     const bool active = i < n;
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
     if (active) {
-        const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i);
+        const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+        if (G.src) G.src[i] = src;
     }
     Analytic a;
     if (gs.on) analytic_closest_block<PTK_BLOCK>(S, gs, active, ro, rd, a);          // block-cooperative: every thread takes part
@@ -260,7 +287,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, 5) k_intersect(SceneView S, int n_a
         if (flag) {
             st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
             st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
-            st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+            if (!S.slim_hits) st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
         } else {
             st4(hits.t_n, i, make_float4(-1.f, 0.f, 0.f, 0.f));
         }
@@ -304,14 +331,16 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __rest
 // the ray's uv_ids slot with flag PTK_VALID_TRI; k_finalize expands it (and clears the list counter for the next bounce).
 template <bool STATS>
 __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
-                                                         PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats) {
+                                                         PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
+                                                         const int* __restrict__ srcidx) {
     const int m = (int)*list_count;
     const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (blockIdx.x * PTK_BLOCK >= m) return;
     unsigned nv = 0, nt = 0;
     if (j < m) {
         const int ray = list[j];
-        const float4 o4 = ld4(paths.o_pix, ray), d4 = ld4(paths.d_bnc, ray);
+        const int src = srcidx ? srcidx[ray] : ray;                    // physical slot of dense path `ray` (segmented streams)
+        const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         const float t0 = hits.t_n[4 * (size_t)ray];                   // analytic closest t, -1 = none
         Walk w;
         walk_begin(S, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), t0 > 0.f ? t0 : FLT_MAX, w);
@@ -347,7 +376,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
             triangle_record(S, __float_as_int(r.w), r.x, r.y, r.z, h);
             st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
             st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
-            st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+            if (!S.slim_hits) st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
             valid[i] = 1;
             flag = 1;
         }
@@ -361,10 +390,12 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
 
 // environment map on a miss (pathtrace.cu:303-311): img[pixel] += processNAN(color * env(sphere2Plane(direction)))
 __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
-                                                         const int* __restrict__ valid, float* __restrict__ img, unsigned plane_stride) {
+                                                         const int* __restrict__ valid, float* __restrict__ img, unsigned plane_stride,
+                                                         const int* __restrict__ srcidx) {
     const int n = d_n ? *d_n : n_arg;
-    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
-    if (i >= n || valid[i] != 0) return;
+    const int g = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (g >= n || valid[g] != 0) return;
+    const int i = srcidx ? srcidx[g] : g;
     const float4 d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)i + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
@@ -469,7 +500,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
     }
     int alive = 0;
     if (flag) {
-        const float4 h0 = ld4(hits.t_n, i), h1 = ld4(hits.p_mat, i), h2 = ld4(hits.uv_ids, i);
+        const float4 h0 = ld4(hits.t_n, i), h1 = ld4(hits.p_mat, i);
+        const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(hits.uv_ids, i);
         const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
         Hit h;
         h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
@@ -501,7 +533,11 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
                                                       const int* __restrict__ d_n, PtkHits hits, PtkPaths paths,
                                                       const int* __restrict__ valid_a, const int* __restrict__ agg_a,
                                                       int* __restrict__ valid_b, int* __restrict__ agg_b,
-                                                      float* __restrict__ img_base, unsigned plane_stride, int spp) {
+                                                      float* __restrict__ img_base, unsigned plane_stride, int spp,
+                                                      const int* __restrict__ srcidx, PtkPaths seg_out) {
+    // srcidx  : physical slot of every dense path (segmented input stream), nullptr = the stream is dense
+    // seg_out : non-null streams = block-local compaction: survivors go to seg_out[b * NT + rank within the block] and agg_b[b] is
+    //           their number (valid_b unused); null = update the paths in place and flag the survivors in valid_b (k_scatter follows)
     constexpr int NW = NT / 64, NKEY = 6, SUB = NT / PTK_BLOCK;      // SUB aggregate entries (256-path ranges) per block
     __shared__ int s_cnt[NW][NKEY];
     __shared__ int s_perm[NT];
@@ -550,23 +586,28 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
     __syncthreads();
     // --- sorted order: thread `tid` shades item src
     int alive = 0, src = -1;
+    PathRegs p;
+    p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
     if (tid < n_active) {
         src = s_perm[tid];
         const int it = b * NT + src;
         const int slot = s_slot[src];
-        const float4 h0 = ld4(hits.t_n, it), h1 = ld4(hits.p_mat, it), h2 = ld4(hits.uv_ids, it);
-        const float4 o4 = ld4(paths.o_pix, it), d4 = ld4(paths.d_bnc, it), c4 = ld4(paths.col_pdf, it);
+        const float4 h0 = ld4(hits.t_n, it), h1 = ld4(hits.p_mat, it);
+        const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(hits.uv_ids, it);
+        const int ps = srcidx ? srcidx[it] : it;
+        const float4 o4 = ld4(paths.o_pix, ps), d4 = ld4(paths.d_bnc, ps), c4 = ld4(paths.col_pdf, ps);
         Hit h;
         h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
         h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
-        PathRegs p;
         p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
         alive = shade_path<MODE>(S, gs, iter, slot, depth, h, p, img);
-        st4(paths.o_pix, it, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
-        st4(paths.d_bnc, it, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
-        st4(paths.col_pdf, it, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+        if (!seg_out.o_pix) {
+            st4(paths.o_pix, ps, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+            st4(paths.d_bnc, ps, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+            st4(paths.col_pdf, ps, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+        }
     }
     __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
     s_slot[tid] = 0;
@@ -574,10 +615,25 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
     if (src >= 0) s_slot[src] = alive;
     __syncthreads();
     const int alive_here = s_slot[tid];
-    if (i < n) valid_b[i] = alive_here;
+    if (!seg_out.o_pix && i < n) valid_b[i] = alive_here;
     const unsigned long long ab = __ballot(alive_here != 0);
     if (lane == 0) s_red[wid] = __popcll(ab);
     __syncthreads();
+    if (seg_out.o_pix) {                   // block-local compaction (NT == PTK_BLOCK): survivor rank in original order
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = s_red[w]; before += (w < wid) ? c : 0; total += c; }
+        s_perm[tid] = before + __popcll(ab & lt);
+        __syncthreads();
+        if (alive) {
+            const int s2 = b * NT + s_perm[src];
+            st4(seg_out.o_pix, s2, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+            st4(seg_out.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+            st4(seg_out.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+        }
+        if (tid == 0) agg_b[b] = total;
+        return;
+    }
     if (tid < SUB && (b * SUB + tid) * PTK_BLOCK < n) {
         int t = 0;
 #pragma unroll
@@ -708,6 +764,37 @@ __device__ __forceinline__ int block_excl_prefix_n(int flag, int& total) {
     return off + within;
 }
 
+// Logical block id of a chained-scan kernel (see k_bounce).  Thread 0 reads the live count, the iteration number and the
+// launch tag, THEN draws the ticket, and hands all four to the block through LDS.  Blocks beyond the live count get b = -1.
+// The block that draws the last ticket resets the ticket, steps the tag and performs the once-per-launch updates.
+template <int NT>
+__device__ __forceinline__ void draw_ticket(const int* d_n, int n_arg, const int* iter_ptr, int iter_arg, unsigned* ticket_ctr, unsigned* epoch,
+                                            int* iter_advance, int iter_stride, unsigned long long* ray_total, int* count_out,
+                                            int& b, unsigned& tag, int& n, int& step) {
+    __shared__ int s_hdr[4];                 // ticket, tag, n, step
+    if (threadIdx.x == 0) {
+        const int n0 = d_n ? *d_n : n_arg;
+        const int step0 = iter_ptr ? *iter_ptr : iter_arg;
+        const unsigned tag0 = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ticket = -1;
+        const int nb = n0 > 0 ? (n0 + NT - 1) / NT : 0;
+        if ((int)blockIdx.x < nb || (nb == 0 && blockIdx.x == 0)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // n, step, tag are in registers before the ticket is drawn
+            if (nb > 0) ticket = (int)atomicAdd(ticket_ctr, 1u);
+            if (nb == 0 || ticket == nb - 1) {                               // every participating block holds its ticket and has read the words above
+                __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(epoch, tag0 + 1u == 0u ? 1u : tag0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (iter_advance) *iter_advance += iter_stride;
+                if (ray_total && n0 > 0) atomicAdd(ray_total, (unsigned long long)n0);
+                if (nb == 0 && count_out) *count_out = 0;
+            }
+        }
+        s_hdr[0] = ticket; s_hdr[1] = (int)tag0; s_hdr[2] = n0; s_hdr[3] = step0;
+    }
+    __syncthreads();
+    b = s_hdr[0]; tag = (unsigned)s_hdr[1]; n = s_hdr[2]; step = s_hdr[3];
+}
+
 struct FusedArgs {
     int iter_arg; const int* iter_ptr; int depth;
     int n_arg; const int* d_n;
@@ -723,31 +810,10 @@ struct FusedArgs {
 
 template <int MODE, bool STATS, int NT>
 __global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
-    __shared__ int s_hdr[4];                 // ticket, tag, n, step
-    if (threadIdx.x == 0) {
-        const int n0 = A.d_n ? *A.d_n : A.n_arg;
-        const int step0 = A.iter_ptr ? *A.iter_ptr : A.iter_arg;
-        const unsigned tag0 = __hip_atomic_load(A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ticket = -1;
-        const int nb = n0 > 0 ? (n0 + NT - 1) / NT : 0;
-        if ((int)blockIdx.x < nb || (nb == 0 && blockIdx.x == 0)) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // n, step, tag are in registers before the ticket is drawn
-            if (nb > 0) ticket = (int)atomicAdd(A.ticket, 1u);
-            if (nb == 0 || ticket == nb - 1) {                               // every participating block holds its ticket and has read the words above
-                __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(A.epoch, tag0 + 1u == 0u ? 1u : tag0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (A.iter_advance) *A.iter_advance += A.iter_stride;
-                if (A.ray_total && n0 > 0) atomicAdd(A.ray_total, (unsigned long long)n0);
-                if (nb == 0 && A.count_out) *A.count_out = 0;
-            }
-        }
-        s_hdr[0] = ticket; s_hdr[1] = (int)tag0; s_hdr[2] = n0; s_hdr[3] = step0;
-    }
-    __syncthreads();
-    const int b = s_hdr[0];
-    const unsigned tag = (unsigned)s_hdr[1];
-    const int n = s_hdr[2];
-    const int iter = (s_hdr[3] - 1) * A.spp + 1;
+    int b, n, step;
+    unsigned tag;
+    draw_ticket<NT>(A.d_n, A.n_arg, A.iter_ptr, A.iter_arg, A.ticket, A.epoch, A.iter_advance, A.iter_stride, A.ray_total, A.count_out, b, tag, n, step);
+    const int iter = (step - 1) * A.spp + 1;
     if (b < 0) return;
     const GeomStage gs = stage_geoms(S);
     const Film img = {A.img, A.plane_stride};
@@ -797,6 +863,50 @@ __global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
     }
 }
 
+// Segmented streams, bookkeeping between two bounces (one block): exclusive prefix of the per-window survivor counts, the
+// window that holds the first path of every dense 256-range, and the live count of the next bounce.  A window holds at
+// most 256 paths, so it contains at most one multiple of 256 of the dense order: seg_first is written by scatter, no search.
+#define PTK_SEG_BLOCK 1024
+__global__ void __launch_bounds__(PTK_SEG_BLOCK) k_segments(int n_arg, const int* __restrict__ d_n, const int* __restrict__ agg, int* __restrict__ pref,
+                                                            int* __restrict__ first, int* __restrict__ count_out, int* iter_advance, int iter_stride) {
+    constexpr int NW = PTK_SEG_BLOCK / 64;
+    __shared__ int s_w[NW];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n_prev = d_n ? *d_n : n_arg;
+    const int nw = n_prev > 0 ? (n_prev + PTK_BLOCK - 1) / PTK_BLOCK : 0;          // windows the shading kernel wrote
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nw; base += PTK_SEG_BLOCK) {
+        const int idx = base + tid;
+        const int v = idx < nw ? agg[idx] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_w[wid] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = s_w[w]; woff += (w < wid) ? c : 0; tot += c; }
+        const int carry = s_carry;
+        const int excl = carry + woff + incl - v;
+        if (idx < nw) {
+            pref[idx] = excl;
+            const int B = (excl + PTK_BLOCK - 1) / PTK_BLOCK;
+            if (v > 0 && B * PTK_BLOCK < excl + v) first[B] = idx;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    const int total = s_carry;
+    if (tid < 8) pref[nw + tid] = total;                   // gather_source reads up to 4 entries past its window
+    if (tid == 0) {
+        if (count_out) *count_out = total;
+        if (iter_advance) *iter_advance += iter_stride;    // last kernel of an iteration: step the device-resident iteration number
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // sendImageToPBO, pathtrace.cu:32-65 (ACESFilm + gammaCorrection, utilities.h:35-48)
 // ------------------------------------------------------------------------------------------------------------------
@@ -842,13 +952,14 @@ int g_shade_bin = 256;                 // 0: plain k_shade; 256/512/1024: k_shad
 
 template <int NT>
 int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                        const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st) {
+                        const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st,
+                        const int* srcidx, PtkPaths seg_out) {
     const int g = (n + NT - 1) / NT;
     if (g == 0) return 0;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, srcidx, seg_out); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, srcidx, seg_out); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, srcidx, seg_out); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -856,10 +967,13 @@ int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_
 
 template <bool V>
 int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                 const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st) {
-    if (V && g_shade_bin == 1024) return launch_shade_binned<1024>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st);
-    if (V && g_shade_bin == 512) return launch_shade_binned<512>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st);
-    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st);
+                 const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st,
+                 const int* srcidx = nullptr, PtkPaths seg_out = PtkPaths{nullptr, nullptr, nullptr}) {
+    if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, srcidx, seg_out);
+    if (srcidx) return PTK_E_BADARG;       // only the segmented pipeline addresses paths indirectly
+    if (V && g_shade_bin == 1024) return launch_shade_binned<1024>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
+    if (V && g_shade_bin == 512) return launch_shade_binned<512>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
+    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
     const int g = grid_for(n);
     if (g == 0) return 0;
     switch (mode) {
@@ -928,24 +1042,24 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
-                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool)) {
+                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
     mark(1, true);
     if (!split) {
-        if (stats) k_intersect<true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats, nullptr, nullptr);
-        else k_intersect<false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr, nullptr, nullptr);
+        if (stats) k_intersect<true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, stats, nullptr, nullptr, G);
+        else k_intersect<false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, agg, ray_total, nullptr, nullptr, nullptr, G);
         mark(1, false);
         return launch_rc();
     }
-    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg);
-    else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg);
+    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg, G);
+    else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg, G);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats);
-    else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr);
+    if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg);
     mark(1, false);
@@ -955,23 +1069,39 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
 // one bounce of the staged pipeline: intersect -> shade (virtual compaction of misses) -> scatter survivors.
 // `capacity` bounds the launch; the live count is read from ws.counts[depth] on the device.
 static void no_mark(int, bool) {}
-int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
+int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
                                   PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce) {
     const int g = grid_for(capacity);
     if (g == 0) return 0;
     const int* d_n = ws.counts + depth;
+    // (uv, geomID, triangleID) of the hit record feed texture lookups and lightPDF only: without textures and outside MIS
+    // the shading kernels never look at them, so that third of the record is neither written nor read
+    SceneView S = S_in;
+    S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
+    // segmented streams: `cur` holds the survivors of the previous bounce window by window (dense at bounce 0)
+    const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && ws.srcidx;
+    Gather G = {nullptr, nullptr, nullptr};
+    if (seg && depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
     // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
-                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark);
+                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G);
     if (rc) return rc;
     if (S.env_tex >= 0) {
-        k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride);
+        k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride, G.src);
         if ((rc = launch_rc())) return rc;
     }
     mark(2, true);
-    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, st);
+    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, st,
+                            G.src, seg ? nxt : PtkPaths{nullptr, nullptr, nullptr});
     mark(2, false);
     if (rc) return rc;
+    if (seg) {                              // survivors are already in nxt, window by window: only the bookkeeping is left
+        mark(3, true);
+        k_segments<<<1, PTK_SEG_BLOCK, 0, st>>>(capacity, d_n, ws.agg_b, ws.seg_pref, ws.seg_first, ws.counts + depth + 1,
+                                                 last_bounce ? ws.iter_dev : nullptr, ws.iter_stride);
+        mark(3, false);
+        return launch_rc();
+    }
     PtkHits none = {nullptr, nullptr, nullptr};
     mark(3, true);
     k_scatter<<<g, PTK_BLOCK, 0, st>>>(capacity, d_n, ws.valid_b, ws.agg_b, cur, none, nxt, none, ws.counts + depth + 1,
@@ -1045,10 +1175,10 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
     }
     const SceneView S = dev_view(*s->scene);
     int rc = launch_intersect_stage(S, n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
-                                    nullptr, nullptr, true, (hipStream_t)stream, [](int, bool) {});
+                                    nullptr, nullptr, true, (hipStream_t)stream, [](int, bool) {}, Gather{nullptr, nullptr, nullptr});
     if (rc || !img || S.env_tex < 0) return rc;
     if (!paths.col_pdf) return PTK_E_BADARG;
-    k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, img, 0u);
+    k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, img, 0u, nullptr);
     return launch_rc();
 }
 
