@@ -416,10 +416,34 @@ __device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
     p[0] += c.x; p[1] += c.y; p[2] += c.z;
 }
 
+// Material records staged in LDS by the shading kernel (first PTK_LDS_MATS materials; the rest, if any, come from global memory):
+// shading otherwise starts with two dependent global loads per path (hit -> material id -> material).
+#define PTK_LDS_MATS 64
+struct MatTable { const DevMaterial* lds; int n_lds; };
+__device__ __forceinline__ DevMaterial fetch_material(const SceneView& S, const MatTable& mt, int id) {
+    if (id < mt.n_lds) return mt.lds[id];
+    return S.mats[id];
+}
+__device__ __forceinline__ int fetch_material_type(const SceneView& S, const MatTable& mt, int id) {
+    if (id < mt.n_lds) return mt.lds[id].type;
+    return S.mats[id].type;
+}
+template <int NT>
+__device__ __forceinline__ MatTable stage_materials(const SceneView& S, DevMaterial* lds) {      // all threads of the block; ends with a barrier
+    const int n = S.n_mats < PTK_LDS_MATS ? S.n_mats : PTK_LDS_MATS;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(S.mats);
+    for (int j = threadIdx.x; j < n * (int)(sizeof(DevMaterial) / 4); j += NT) dst[j] = src[j];
+    __syncthreads();
+    MatTable mt; mt.lds = lds; mt.n_lds = n;
+    return mt;
+}
+
 template <int MODE>
-__device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& gs, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
+__device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& gs, const MatTable& mt, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
     if (h.t <= 0.f) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
-    const MatEval m = eval_material(S, S.mats[h.mat], h.uv);
+    const DevMaterial mrec = fetch_material(S, mt, h.mat);
+    const MatEval m = eval_material(S, mrec, h.uv);
     Rng rng = make_rng(iter, slot, depth);
     if (MODE == PTK_MODE_DIRECTLI) {
         if (m.type == PTK_MAT_LIGHT) {
@@ -510,7 +534,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
         p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-        alive = shade_path<MODE>(S, gs, iter, slot, depth, h, p, img);
+        const MatTable mt = {nullptr, 0};
+        alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
         st4(paths.o_pix, i, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
         st4(paths.d_bnc, i, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
         st4(paths.col_pdf, i, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
@@ -550,12 +575,16 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
     if (b * NT >= n) return;
     GeomStage gs; gs.xf = nullptr; gs.on = false;
     if (MODE != PTK_MODE_BSDF) gs = stage_geoms(S);
+    __shared__ DevMaterial s_mats[PTK_LDS_MATS];
+    const MatTable mt = stage_materials<NT>(S, s_mats);
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // --- original order: flag, compacted slot, material key
     const int flag = (i < n) ? valid_a[i] : 0;
+    __shared__ int s_src[NT];
+    s_src[tid] = (srcidx && i < n) ? srcidx[i] : i;          // physical slot of this dense position, handed to whoever shades it
     int key = NKEY - 1;
-    if (flag) key = S.mats[__float_as_int(hits.p_mat[4 * (size_t)i + 3])].type;
+    if (flag) key = fetch_material_type(S, mt, __float_as_int(hits.p_mat[4 * (size_t)i + 3]));
     unsigned long long bal[NKEY];
 #pragma unroll
     for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
@@ -594,7 +623,7 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
         const int slot = s_slot[src];
         const float4 h0 = ld4(hits.t_n, it), h1 = ld4(hits.p_mat, it);
         const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(hits.uv_ids, it);
-        const int ps = srcidx ? srcidx[it] : it;
+        const int ps = s_src[src];
         const float4 o4 = ld4(paths.o_pix, ps), d4 = ld4(paths.d_bnc, ps), c4 = ld4(paths.col_pdf, ps);
         Hit h;
         h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
@@ -602,7 +631,7 @@ __global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, 
         p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-        alive = shade_path<MODE>(S, gs, iter, slot, depth, h, p, img);
+        alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
         if (!seg_out.o_pix) {
             st4(paths.o_pix, ps, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
             st4(paths.d_bnc, ps, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
@@ -843,7 +872,8 @@ __global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
     if (flag) {
         const float4 c4 = ld4(A.cur.col_pdf, i);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-        alive = shade_path<MODE>(S, gs, iter, prior + local, A.depth, h, p, img);
+        const MatTable mt = {nullptr, 0};
+        alive = shade_path<MODE>(S, gs, mt, iter, prior + local, A.depth, h, p, img);
     }
     int total2;
     const int local2 = block_excl_prefix_n<NT>(alive, total2);
@@ -877,9 +907,12 @@ __global__ void __launch_bounds__(PTK_SEG_BLOCK) k_segments(int n_arg, const int
     const int nw = n_prev > 0 ? (n_prev + PTK_BLOCK - 1) / PTK_BLOCK : 0;          // windows the shading kernel wrote
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int base = 0; base < nw; base += PTK_SEG_BLOCK) {
-        const int idx = base + tid;
-        const int v = idx < nw ? agg[idx] : 0;
+    for (int base = 0; base < nw; base += 4 * PTK_SEG_BLOCK) {             // four consecutive windows per thread: one pass up to 4096 windows
+        const int idx = base + 4 * tid;
+        int4 c = make_int4(0, 0, 0, 0);
+        if (idx + 3 < nw) c = *reinterpret_cast<const int4*>(agg + idx);  // agg is 16-byte aligned (hipMalloc) and idx % 4 == 0
+        else { if (idx < nw) c.x = agg[idx]; if (idx + 1 < nw) c.y = agg[idx + 1]; if (idx + 2 < nw) c.z = agg[idx + 2]; }
+        const int v = c.x + c.y + c.z + c.w;
         int incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -887,13 +920,18 @@ __global__ void __launch_bounds__(PTK_SEG_BLOCK) k_segments(int n_arg, const int
         __syncthreads();
         int woff = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { const int c = s_w[w]; woff += (w < wid) ? c : 0; tot += c; }
+        for (int w = 0; w < NW; ++w) { const int cw = s_w[w]; woff += (w < wid) ? cw : 0; tot += cw; }
         const int carry = s_carry;
-        const int excl = carry + woff + incl - v;
-        if (idx < nw) {
-            pref[idx] = excl;
-            const int B = (excl + PTK_BLOCK - 1) / PTK_BLOCK;
-            if (v > 0 && B * PTK_BLOCK < excl + v) first[B] = idx;
+        int excl = carry + woff + incl - v;
+        const int cnt[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (idx + k < nw) {
+                pref[idx + k] = excl;
+                const int B = (excl + PTK_BLOCK - 1) / PTK_BLOCK;
+                if (cnt[k] > 0 && B * PTK_BLOCK < excl + cnt[k]) first[B] = idx + k;
+            }
+            excl += cnt[k];
         }
         __syncthreads();
         if (tid == 0) s_carry = carry + tot;
