@@ -241,7 +241,7 @@ def main():
                        "sharding": "none" if N == 1 else (f"interleaved row tiles of {a.tile_rows} rows (tile % {N} == rank), {spp} sample(s) of the owned "
                                                           f"pixels per launch, one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
-                       "pipeline": "staged: intersect / shade / scatter per bounce, device-resident counts, no host sync"},
+                       "pipeline": "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync"},
             "device_ms_per_step": round(dev_ms / a.steps, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -168,6 +168,12 @@ int ptk_set_samples_per_launch(int spp);
  * is counting-sorted by material type in LDS before shading, to cut BSDF-switch divergence (default 256; measured gain on MI355X is small, 1-5 %).  Every path keeps
  * its own RNG key and state, so results are identical. */
 int ptk_set_shade_binning(int block);
+/* Opt-in "fixed" cube lights.  The reference's LightSampler gives cube lights neither a sampled position nor a
+ * pdf (lightSample.h:141-248): MIS renders of cube-lit scenes (cornell.txt) are darkened and direct lighting from them is
+ * black.  on = 1: a cube light is sampled uniformly over its surface (face in proportion to world-space area) with the
+ * area -> solid-angle pdf of a triangle light, and lightPDF returns the same for a BSDF-sampled hit; MIS and BSDF renders
+ * then converge to the same image.  Default 0 = reference behaviour.  Applies to the kernels launched afterwards. */
+int ptk_set_light_fix(int on);
 /* Threads per block of the fused bounce kernel (pipeline 3): 256 (default) or 512.  Identical results. */
 int ptk_set_fused_block(int threads);
 /* 1: replay every iteration from a hipGraph captured once per lane (the kernels then read the iteration number from device
@@ -192,19 +198,22 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
 /* Pipeline selection (A/B comparisons; all produce identical results):
- *   0 = staged, three kernel classes per bounce (intersect / shade / scatter) with device-resident counts.  Scenes with
- *       triangles run the work-list BVH layout (analytic primitives + root-box test, stable compaction of the rays that enter
- *       the root box, BVH walk over the list, finalize);
- *   1 = staged, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
+ *   0 = default.  Per bounce: intersect stage, shading with block-local compaction of the survivors, window prefix
+ *       (k_segments); the next bounce addresses paths through the window tables, so surviving path state is written once
+ *       and never moved.  Scenes with triangles run the work-list BVH layout in the intersect stage (analytic primitives +
+ *       root-box test, stable compaction of the rays that enter the root box, BVH walk over the list, finalize);
+ *   1 = like 0, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
  *   2 = like 1, and analytic primitives are tested with wave-uniform loops over every primitive instead of the LDS-staged
- *       per-lane candidate loops;
- *   3 = fused: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans; the hit
- *       record never leaves registers, one third of the staged layout's memory traffic). */
+ *       candidate pair lists;
+ *   3 = fused: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans with
+ *       ticketed block ids; the hit record never leaves registers).  Least memory traffic, but the ticket counter
+ *       serialises block starts (~11 ns each): slower than 0 on MI355X at the BASELINE sizes;
+ *   4 = like 0 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables. */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 
 /* Per-kernel device time, measured with HIP events ON THE RENDER STREAM around every launch of the ptk_pathtrace calls
- * issued between begin and end.  ms4/launches4: [0] generate, [1] intersect, [2] shade, [3] scatter.  Diagnostic only
+ * issued between begin and end.  ms4/launches4: [0] generate, [1] intersect (pipeline 3: the fused kernel), [2] shade, [3] compact (k_segments / k_scatter).  Diagnostic only
  * (adds an event pair per launch): never used inside a timed region. */
 int ptk_profile_begin(void);
 int ptk_profile_end(float* ms4, int* launches4);

@@ -847,6 +847,19 @@ static float matPDF(const Material& m, const Isect& is, v3 wo, v3 wi) {
 // ---------------------------------------------------------------------------------------
 struct LightRec { v3 pos, emit; float pdf = 0; };   // pdf is uninitialised in the reference; 0 here (only read when lightSize==0)
 
+// ---- opt-in "fixed" cube lights (NOT reference behaviour, off by default) -------------------------------
+// The reference gives cube lights neither a sampled position nor a pdf (lightSample.h:141-248), which darkens MIS renders
+// of scenes lit by cubes (cornell.txt).  With the fix on, a cube light is sampled uniformly over its surface — face chosen
+// in proportion to its world-space area, uniform point on the face — with the same area -> solid-angle pdf as a triangle
+// light, pdf = (1/L) d^2 / (A |cos|), A = the cube's total area, and lightPDF returns the same for a BSDF-sampled hit.
+static int g_light_fix = 0;
+// world-space areas of the three face pairs (x, y, z) of a unit cube under `transform`, and their sum times two
+static inline void cubeFaceAreas(const Geom& g, float a[3], float& total) {
+    v3 ex = mulMV(g.transform, v3(1.f, 0.f, 0.f), 0.f), ey = mulMV(g.transform, v3(0.f, 1.f, 0.f), 0.f), ez = mulMV(g.transform, v3(0.f, 0.f, 1.f), 0.f);
+    a[0] = length(cross(ey, ez)); a[1] = length(cross(ez, ex)); a[2] = length(cross(ex, ey));
+    total = 2.f * ((a[0] + a[1]) + a[2]);
+}
+
 // lightSample.h:141-169
 static float lightPDF(const OrcScene& S, v3 viewPos, v3 lightPos, v3 normal, int triID, int geomID) {
     float pdf = -1.f;
@@ -863,6 +876,12 @@ static float lightPDF(const OrcScene& S, v3 viewPos, v3 lightPos, v3 normal, int
         float sinThetaMax2 = (0.5f * 0.5f) / dot(viewPosL, viewPosL);      // (viewPosL - 0) == viewPosL
         float cosThetaMax = sqrtf(std::max(0.0f, 1.0f - sinThetaMax2));
         pdf = 1.0f / (TWO_PI_F * (1 - cosThetaMax) * L);
+    }
+    if (g_light_fix && triID < 0 && S.geoms[geomID].type == GEOM_CUBE) {
+        float a[3], area; cubeFaceAreas(S.geoms[geomID], a, area);
+        pdf = 1.f / L;
+        v3 dlt = lightPos - viewPos;
+        pdf = pdf * dot(dlt, dlt) / (area * fabsf(dot(normalize(viewPos - lightPos), normal)));
     }
     return pdf;
 }
@@ -909,7 +928,28 @@ static void lightSample(const OrcScene& S, v3 viewPos, Rng rng, LightRec& rec) {
         lightPos = mulMV(geom.transform, pObj, 1.0f);
         pdf = 1.0f / (TWO_PI_F * (1 - cosThetaMax) * L);
     }
-    // cube lights: nothing assigned -> lightPos = 0, pdf = 0
+    else if (g_light_fix && light.type == GEOM_CUBE) {
+        float a[3], area; cubeFaceAreas(geom, a, area);
+        float uf = sample1D(rng) * area;
+        v2 r = sample2D(rng);
+        int axis = 2; float sg = -1.f, acc = 0.f;                               // faces in the order +x -x +y -y +z -z
+        bool done = false;
+        for (int k = 0; k < 3 && !done; ++k) for (int s2 = 0; s2 < 2 && !done; ++s2) {
+            acc = acc + a[k];
+            if (uf < acc) { axis = k; sg = s2 == 0 ? 1.f : -1.f; done = true; }
+        }
+        v3 pObj, nObj;
+        float c0 = r.x - 0.5f, c1 = r.y - 0.5f;
+        if (axis == 0) { pObj = v3(0.5f * sg, c0, c1); nObj = v3(sg, 0.f, 0.f); }
+        else if (axis == 1) { pObj = v3(c1, 0.5f * sg, c0); nObj = v3(0.f, sg, 0.f); }
+        else { pObj = v3(c0, c1, 0.5f * sg); nObj = v3(0.f, 0.f, sg); }
+        lightPos = mulMV(geom.transform, pObj, 1.0f);
+        normal = normalize(mulMV(geom.invTranspose, nObj, 0.0f));
+        pdf = 1.f / L;
+        v3 dlt = lightPos - viewPos;
+        pdf = pdf * dot(dlt, dlt) / (area * fabsf(dot(normalize(viewPos - lightPos), normal)));
+    }
+    // cube lights (reference behaviour): nothing assigned -> lightPos = 0, pdf = 0
     v3 rayDir = normalize(lightPos - viewPos);
     if (occlusionTest(S, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = v3(); rec.pdf = -1.f; return; }
     rec.emit = v3(lightMat.albedo[0], lightMat.albedo[1], lightMat.albedo[2]);
@@ -1390,6 +1430,7 @@ static void setDevData(OrcScene& S) {
 extern "C" {
 
 void orc_set_trig_mode(int m) { g_trig_mode = m; }
+void orc_set_light_fix(int on) { g_light_fix = on ? 1 : 0; }
 int orc_get_trig_mode() { return g_trig_mode; }
 
 // Scene(file) + main.cpp camera fix-ups + setDevData.  res_w/res_h/depth <= 0 keep the file's values.

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
-    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_fused_block",
+    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_fused_block", "ptk_set_light_fix",
 ]
 
 
@@ -132,6 +132,7 @@ def _load() -> C.CDLL:
     lib.ptk_set_samples_per_launch.argtypes = [ci]
     lib.ptk_set_shade_binning.argtypes = [ci]
     lib.ptk_set_fused_block.argtypes = [ci]
+    lib.ptk_set_light_fix.argtypes = [ci]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
     lib.ptk_profile_end.argtypes = [vp, vp]
     lib.ptk_enable_traversal_stats.argtypes = [ci]
@@ -269,6 +270,11 @@ def tonemap(img, w: int, h: int, it: int, pbo):
 # ---------------------------------------------------------------------------------------------
 # render API (pathtraceInit / pathtrace / pathtraceFree through the C ABI)
 # ---------------------------------------------------------------------------------------------
+def set_light_fix(on: bool) -> None:
+    """Opt-in fixed cube lights (ptk_set_light_fix; not reference behaviour, default off)."""
+    _chk(lib.ptk_set_light_fix(1 if on else 0), "ptk_set_light_fix")
+
+
 class Renderer:
     """File-static render context of the library (one at a time, like the reference)."""
 
@@ -325,10 +331,10 @@ class Renderer:
         _chk(lib.ptk_profile_begin(), "ptk_profile_begin")
 
     def profile_end(self):
-        """-> {class: (total_ms, launches)} for generate / intersect / shade / scatter"""
+        """-> {class: (total_ms, launches)} for generate / intersect / shade / compact (k_segments, or k_scatter in pipeline 4)"""
         ms = np.zeros(4, np.float32); n = np.zeros(4, np.int32)
         _chk(lib.ptk_profile_end(ms.ctypes.data, n.ctypes.data), "ptk_profile_end")
-        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(("generate", "intersect", "shade", "scatter"))}
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(("generate", "intersect", "shade", "compact"))}
 
     def traversal_stats(self, enable=None):
         if enable is not None:

@@ -98,6 +98,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--res") && i + 2 < argc) { rw = std::atoi(argv[++i]); rh = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else if (!std::strcmp(argv[i], "--light-fix")) ptk_set_light_fix(1);        // opt-in fixed cube lights (not reference behaviour)
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::printf("No HIP-capable devices were detected.\n"); return 2; }

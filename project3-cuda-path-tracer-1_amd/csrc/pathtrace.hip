@@ -318,6 +318,8 @@ int ptk_set_iterations_in_flight(int lanes) {
 /* Shading kernel layout: 0 = one path per thread in path order; 256 / 512 / 1024 = paths of a block of that many consecutive
  * paths are counting-sorted by material type before shading (default 256).  Identical results. */
 int ptk_set_shade_binning(int block) { if (block != 0 && block != 256 && block != 512 && block != 1024) return PTK_E_BADARG; set_shade_bin(block); return 0; }
+/* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
+int ptk_set_light_fix(int on) { set_light_fix(on != 0); return 0; }
 int ptk_set_fused_block(int threads) { if (threads != 256 && threads != 512) return PTK_E_BADARG; set_fused_block(threads); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
 int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }

@@ -158,6 +158,7 @@ struct SceneView {
     const DevLight* lights;      int n_lights;
     const DevTex* tex;           const float* texels;   int env_tex;     // env_tex = envMapID (-1: none)
     int n_tex;                   // number of textures
+    int light_fix;               // opt-in fixed cube lights (ptk_set_light_fix), 0 = reference behaviour
     int slim_hits;               // render pipeline only: 1 = the (uv, geomID, triangleID) third of the hit record is unused
 };
 
@@ -847,6 +848,14 @@ PTK_DI float mat_pdf(const MatEval& m, f3 n, f3 wo, f3 wi) {     // Material::pd
 struct LightRec { f3 pos, emit; float pdf; bool is_zero; };
 
 // LightSampler::lightPDF, lightSample.h:141-169
+// Opt-in "fixed" cube lights (ptk_set_light_fix; NOT reference behaviour): world-space areas of the three face
+// pairs of the unit cube under the primitive's transform; total = the cube's surface area.
+PTK_DI void cube_face_areas(const DevGeom& g, float a[3], float& total) {
+    const f3 ex = mk3(g.fwd[0], g.fwd[4], g.fwd[8]), ey = mk3(g.fwd[1], g.fwd[5], g.fwd[9]), ez = mk3(g.fwd[2], g.fwd[6], g.fwd[10]);
+    a[0] = length(cross(ey, ez)); a[1] = length(cross(ez, ex)); a[2] = length(cross(ex, ey));
+    total = 2.f * ((a[0] + a[1]) + a[2]);
+}
+
 PTK_DI float light_pdf(const SceneView& S, f3 viewPos, f3 lightPos, f3 normal, int triID, int geomID) {
     float pdf = -1.f;
     float L = (float)S.n_lights;
@@ -864,6 +873,12 @@ PTK_DI float light_pdf(const SceneView& S, f3 viewPos, f3 lightPos, f3 normal, i
         float s2 = (0.5f * 0.5f) / dot(vl, vl);
         float cmax = sqrtf(smax(0.0f, 1.0f - s2));
         pdf = 1.0f / (PTK_TWO_PI * (1 - cmax) * L);
+    }
+    if (S.light_fix && triID < 0 && g.type == 1) {          // fixed cube light: area pdf over the whole surface -> solid angle
+        float a[3], area; cube_face_areas(g, a, area);
+        pdf = 1.f / L;
+        f3 dl = lightPos - viewPos;
+        pdf = pdf * dot(dl, dl) / (area * fabsf(dot(normalize(viewPos - lightPos), normal)));
     }
     return pdf;
 }
@@ -911,6 +926,33 @@ PTK_DI void light_sample(const SceneView& S, const GeomStage& gs, const DevMater
         f3 pObj = nObj * 0.5f;
         lightPos = xform_point(geom.fwd, pObj);
         pdf = 1.0f / (PTK_TWO_PI * (1 - cmax) * L);
+    } else if (S.light_fix && light.type == 1) {
+        // fixed cube light: face in proportion to its area (+x -x +y -y +z -z), uniform point on it
+        float a[3], area; cube_face_areas(geom, a, area);
+        const float uf = sample1D(rng) * area;
+        const f2 r = sample2D(rng);
+        int axis = 2; float sg = -1.f, acc = 0.f;
+        bool done = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (!done) {
+                    acc = acc + a[k];
+                    if (uf < acc) { axis = k; sg = s2 == 0 ? 1.f : -1.f; done = true; }
+                }
+            }
+        }
+        const float c0 = r.x - 0.5f, c1 = r.y - 0.5f;
+        f3 pObj, nObj;
+        if (axis == 0) { pObj = mk3(0.5f * sg, c0, c1); nObj = mk3(sg, 0.f, 0.f); }
+        else if (axis == 1) { pObj = mk3(c1, 0.5f * sg, c0); nObj = mk3(0.f, sg, 0.f); }
+        else { pObj = mk3(c0, c1, 0.5f * sg); nObj = mk3(0.f, 0.f, sg); }
+        lightPos = xform_point(geom.fwd, pObj);
+        const f3 normal = normalize(xform_nrm(geom.invT, nObj));
+        pdf = 1.f / L;
+        f3 dl = lightPos - viewPos;
+        pdf = pdf * dot(dl, dl) / (area * fabsf(dot(normalize(viewPos - lightPos), normal)));
     } else {
         // cube light: the reference assigns neither position nor pdf; the sample evaluates to 0 / NaN->0 whatever
         // the occlusion test returns (see file header), so the shadow ray is not traced.

@@ -12,6 +12,8 @@ struct PtkScene {
 
 namespace ptk {
 
+void set_light_fix(bool on);            // opt-in fixed cube lights (ptk_set_light_fix)
+bool light_fix_enabled();
 void set_uniform_analytic(bool on);     // A/B: disable the staged candidate loops (ptk_set_pipeline(2))
 bool uniform_analytic();
 
@@ -28,7 +30,7 @@ inline SceneView dev_view(const ::Scene& s) {
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
     d.tex = (const DevTex*)t.dev_textures;       d.texels = (const float*)t.dev_texture_data; d.env_tex = t.envMapID;
-    d.n_tex = t.tex_num; d.slim_hits = 0;
+    d.n_tex = t.tex_num; d.slim_hits = 0; d.light_fix = light_fix_enabled() ? 1 : 0;
     return d;
 }
 

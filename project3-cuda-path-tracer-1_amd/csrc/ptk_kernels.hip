@@ -1172,6 +1172,9 @@ int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int c
     }
 }
 void set_fused_block(int nt) { g_fused_block = (nt == 512) ? 512 : 256; }
+bool g_light_fix = false;
+void set_light_fix(bool on) { g_light_fix = on; }
+bool light_fix_enabled() { return g_light_fix; }
 void set_uniform_analytic(bool on) { g_uniform_analytic = on; }
 bool uniform_analytic() { return g_uniform_analytic; }
 void set_shade_bin(int nt) { g_shade_bin = (nt == 256 || nt == 512 || nt == 1024) ? nt : 0; }

@@ -70,10 +70,16 @@ L.orc_pathtrace_batch.restype = C.c_longlong; L.orc_pathtrace_batch.argtypes = [
 L.orc_stats.argtypes = [vp, ci]
 L.orc_tonemap.argtypes = [vp, ci, ci, vp]
 L.orc_set_trig_mode.argtypes = [ci]
+L.orc_set_light_fix.argtypes = [ci]
 
 
 def set_trig_mode(m):
     L.orc_set_trig_mode(m)
+
+
+def set_light_fix(on):
+    """opt-in fixed cube lights (not reference behaviour)"""
+    L.orc_set_light_fix(1 if on else 0)
 
 
 def f32(*v):

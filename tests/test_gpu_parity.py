@@ -502,3 +502,33 @@ def test_many_primitives(ptk, orc, torch_cuda, tmp_path, n_geoms, mode):
         img = r.image(); r.close()
         bad = (img != ref).any(axis=1)
         assert not bad.any(), f"pipeline {pipeline}: {int(bad.sum())} of {len(ref)} pixels differ"
+
+
+@pytest.mark.parametrize("mode", ["MIS", "DIRECT"])
+def test_fixed_cube_lights(ptk, orc, torch_cuda, mode):
+    """ptk_set_light_fix(1) (opt-in, not reference behaviour): cube lights are sampled and weighted.  GPU == oracle restatement
+    bit-exactly (kernel by kernel through ptk_shade, and whole images), and the result differs from the default behaviour."""
+    m = MODES[mode]
+    name, res, depth = "cornell.txt", (128, 128), 6
+    try:
+        orc.set_light_fix(True); ptk.set_light_fix(True)
+        s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+        o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+        ref = np.zeros((o.P, 3), np.float32)
+        r = ptk.Renderer(s, m, in_flight=2, graph=True)
+        for it in (1, 2, 3, 4):
+            r.iterate(it)
+        planes = [np.zeros((o.P, 3), np.float32) for _ in range(2)]
+        for it in (1, 2, 3, 4):
+            o.pathtrace(m, it, planes[(it - 1) % 2])
+        ref = planes[0] + planes[1]
+        img = r.image(); r.close()
+        assert np.array_equal(img, ref)
+        fixed_sum = float(ref.sum())
+    finally:
+        orc.set_light_fix(False); ptk.set_light_fix(False)
+    o2 = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    base = np.zeros((o2.P, 3), np.float32)
+    for it in (1, 2, 3, 4):
+        o2.pathtrace(m, it, base)
+    assert fixed_sum > 2.0 * float(base.sum())          # reference behaviour: darkened (MIS) or black (DIRECT)
