@@ -164,8 +164,8 @@ int ptk_set_iterations_in_flight(int lanes);
  * own radiance plane; the image is the sum of the planes in order.  Used with the tile partition so that a rank that owns
  * 1/N of the pixels still launches full-size kernels (multi-GPU weak scaling).  Not a reference feature. */
 int ptk_set_samples_per_launch(int spp);
-/* Shading kernel layout: 0 = one path per thread in path order; 256 / 512 / 1024 = each block of that many consecutive paths
- * is counting-sorted by material type in LDS before shading, to cut BSDF-switch divergence (default 256; measured gain on MI355X is small, 1-5 %).  Every path keeps
+/* Shading kernel layout: 256 (default) = each block of 256 consecutive paths is counting-sorted by material type in LDS before
+ * shading, to cut BSDF-switch divergence; 0 = one path per thread in path order (honoured by pipeline 4 only).  Every path keeps
  * its own RNG key and state, so results are identical. */
 int ptk_set_shade_binning(int block);
 /* Opt-in "fixed" cube lights.  The reference's LightSampler gives cube lights neither a sampled position nor a

@@ -315,9 +315,10 @@ int ptk_set_iterations_in_flight(int lanes) {
     return 0;
 }
 
-/* Shading kernel layout: 0 = one path per thread in path order; 256 / 512 / 1024 = paths of a block of that many consecutive
- * paths are counting-sorted by material type before shading (default 256).  Identical results. */
-int ptk_set_shade_binning(int block) { if (block != 0 && block != 256 && block != 512 && block != 1024) return PTK_E_BADARG; set_shade_bin(block); return 0; }
+/* Shading kernel layout: 256 (default) = the paths of each 256-path block are counting-sorted by material type before shading;
+ * 0 = one path per thread in path order (honoured by pipeline 4 only: block-local compaction needs the binned kernel).
+ * 512- and 1024-path bins were measured slower and are gone.  Identical results. */
+int ptk_set_shade_binning(int block) { if (block != 0 && block != 256) return PTK_E_BADARG; set_shade_bin(block); return 0; }
 /* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
 int ptk_set_light_fix(int on) { set_light_fix(on != 0); return 0; }
 int ptk_set_fused_block(int threads) { if (threads != 256 && threads != 512) return PTK_E_BADARG; set_fused_block(threads); return 0; }

@@ -1,20 +1,26 @@
 // ptk_kernels.hip — HIP kernels of the path-tracing hot path for gfx950 + their C-ABI launchers.
 //
-// One kernel per reference kernel (src/pathtrace.cu), re-designed for CDNA4:
-//   k_generate   <- generateRayFromCamera (135-163)
-//   k_intersect  <- computeIntersections  (169-346)
-//   k_shade<M>   <- PTkernel / DirectLiPTkernel / MisPTkernel (348-588)
-//   k_count + k_scatter <- compact_rays (614-631; thrust exclusive_scan + 2x scatter_if + 2 blocking D2H)
-//   k_tonemap    <- sendImageToPBO (32-65)
-// Differences that matter on MI355X:
+// Reference kernel (src/pathtrace.cu) -> kernels here:
+//   generateRayFromCamera (135-163)                       -> k_generate
+//   computeIntersections  (169-346)                       -> k_intersect (+ k_list, k_traverse, k_finalize for scenes with triangles)
+//   PTkernel / DirectLiPTkernel / MisPTkernel (348-588)   -> k_shade_binned<M> (render pipeline), k_shade<M> (kernel-level ABI)
+//   compact_rays (614-631; thrust scan + 2x scatter_if + 2 blocking D2H), twice per bounce
+//                                                         -> nothing moves: virtual compaction of the hits + block-local compaction
+//                                                            of the survivors + k_segments (window tables); k_count + k_scatter
+//                                                            remain as the stand-alone stable compaction (ptk_compact, pipeline 4)
+//   sendImageToPBO (32-65)                                -> k_tonemap
+//   (whole bounce in one launch, A/B only)                -> k_bounce (pipeline 3)
+// What is specific to MI355X:
 //   * 256-thread blocks = 4 wave64; all state streams are float4 SoA (16 B/lane, 1 KiB per wave access);
-//   * scene constants (primitives, materials) are read with wave-uniform indices -> scalar loads / SGPR operands;
-//   * path counts never leave the device: every kernel takes an optional device-resident count, and the
-//     stable compaction is wave-ballot + block prefix + a per-block aggregate table, so a whole iteration is
-//     enqueued without a single host synchronisation;
-//   * in the render pipeline the first compaction of each bounce is *virtual*: the shading kernel derives each
-//     path's compacted slot (the reference's RNG key) from the intersect stage's flags and aggregates, so hit
-//     records are never moved, and surviving path state is moved once per bounce.
+//   * scene constants are read with wave-uniform indices through the constant address space -> scalar loads / SGPR operands;
+//     per-lane primitive and material records come from LDS copies staged once per block;
+//   * analytic primitives: conservative candidate test, then the block's (ray, primitive) pairs balanced over all lanes
+//     through an LDS list, closest hit by ds_min_u64 (analytic_closest_block);
+//   * path counts never leave the device: every kernel takes a device-resident count, so a whole iteration is enqueued
+//     (or replayed from a hipGraph) without a single host synchronisation;
+//   * the reference's two compactions per bounce are index arithmetic: a hit path's compacted slot (its RNG key) comes from
+//     the intersect flags + per-block aggregates, survivors are written once, block-locally, and found again through the
+//     window prefix (gather_source).  See DESIGN.md section 4/5.
 #include "ptk_internal.h"
 
 using namespace ptk;
@@ -986,7 +992,7 @@ DevCamera to_dev_camera(const PtkCamera& c) {
     return d;
 }
 
-int g_shade_bin = 256;                 // 0: plain k_shade; 256/512/1024: k_shade_binned block size (paths sorted by material)
+int g_shade_bin = 256;                 // 0: plain k_shade (pipeline 4 only); 256: k_shade_binned (paths of a block sorted by material)
 
 template <int NT>
 int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
@@ -1009,8 +1015,6 @@ int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, in
                  const int* srcidx = nullptr, PtkPaths seg_out = PtkPaths{nullptr, nullptr, nullptr}) {
     if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, srcidx, seg_out);
     if (srcidx) return PTK_E_BADARG;       // only the segmented pipeline addresses paths indirectly
-    if (V && g_shade_bin == 1024) return launch_shade_binned<1024>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
-    if (V && g_shade_bin == 512) return launch_shade_binned<512>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
     if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
     const int g = grid_for(n);
     if (g == 0) return 0;
@@ -1177,7 +1181,7 @@ void set_light_fix(bool on) { g_light_fix = on; }
 bool light_fix_enabled() { return g_light_fix; }
 void set_uniform_analytic(bool on) { g_uniform_analytic = on; }
 bool uniform_analytic() { return g_uniform_analytic; }
-void set_shade_bin(int nt) { g_shade_bin = (nt == 256 || nt == 512 || nt == 1024) ? nt : 0; }
+void set_shade_bin(int nt) { g_shade_bin = (nt == 256) ? nt : 0; }
 
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st) {
     const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
