@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> "<counters>" <bench args...>  -> gpurun_out/pmc_<tag>/ per-dispatch counter CSV (rocprofv3 --pmc)
+# usage: tools/pmc.sh <tag> "<counters>" <bench args...>  -> gpurun_out/pmc_<tag>/ per-dispatch counter CSV (rocprofv3 --pmc)
 set -o pipefail
 tag=$1; ctrs=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,4 @@
-"""Aggregates the FETCH_SIZE / WRITE_SIZE passes of tools_refresh_profiles.sh into the per-launch HBM traffic of the intersect
+"""Aggregates the FETCH_SIZE / WRITE_SIZE passes of tools/refresh_profiles.sh into the per-launch HBM traffic of the intersect
 kernel (bench.py's roofline.traffic).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide
 coalesced read (MI355X_MICROARCH.md, HBM / rocprofv3 section), hence the doubling."""
 import collections
@@ -25,7 +25,7 @@ def per_dispatch(path, kernel_prefix):
 
 def main(out):
     res = {"_how": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --scene S --steps 4 --warmup 1 --in-flight 1 --graph 0; one counter per pass "
-                   "(tools_refresh_profiles.sh); FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md); averages per dispatch of the "
+                   "(tools/refresh_profiles.sh); FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md); averages per dispatch of the "
                    "kernel named, all bounces", "scenes": {}}
     for scene, tag in (("cornell.txt", "cornell"), ("bunny_cornell.txt", "bunny_cornell")):
         entry = {}

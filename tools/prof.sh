@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> <bench args...>   -> gpurun_out/prof_<tag>/ kernel trace + stats (rocprofv3)
+# usage: tools/prof.sh <tag> <bench args...>   -> gpurun_out/prof_<tag>/ kernel trace + stats (rocprofv3)
 set -o pipefail
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): refreshes every measurement the docs cite into gpurun_out/final/.
+# Runs on the GPU box (gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'): refreshes every measurement the docs cite into gpurun_out/final/.
 #   kernel stats : rocprofv3 --kernel-trace --stats of `python3 bench.py` (cornell, then the BVH scene)
 #   traffic      : rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, single stream, eager launches
 #   bench        : the plain default `python3 bench.py` line
@@ -18,6 +18,6 @@ for sc in cornell.txt bunny_cornell.txt; do
   echo "done $sc"
 done
 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
-python3 tools_pmc_traffic.py $out > $out/pmc_traffic.json || exit 1
+python3 tools/pmc_traffic.py $out > $out/pmc_traffic.json || exit 1
 find $out -name "*.csv" -size +2M -delete
 tail -c 600 $out/bench.json

@@ -1,11 +1,12 @@
 """Quick A/B timing helper (GPU box): ms/iteration and Mrays/s of a scene for given lanes / pipeline."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
 
 
 def run(scn, mode=0, lanes=1, pipeline=0, steps=32, res=None, depth=-1, graph=True):
-    scene = ptk.Scene(os.path.join("scenes", scn), res=res, depth=depth)
+    scene = ptk.Scene(os.path.join(ROOT, "scenes", scn), res=res, depth=depth)
     r = ptk.Renderer(scene, mode, pipeline=pipeline, in_flight=lanes, graph=graph)
     for it in range(1, 9): r.iterate(it)
     r.sync(); r0 = r.ray_total(); r.timer_start()
