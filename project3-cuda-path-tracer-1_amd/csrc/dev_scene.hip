@@ -76,11 +76,12 @@ int DevScene::initiate(Scene& scene) {
                 b.s[2 * r] = std::nextafter((float)(lo[r] - pad), -inf);
                 b.s[2 * r + 1] = std::nextafter((float)(hi[r] + pad), inf);
             }
+            bool round = false;
             if (s.type == SPHERE) {                      // PTK_CAND_QUAD: per-ray pad qa + qb * |o|^2
-                double smin = 1e300, smax = 0.0, cc = 0.0;
+                double smin = 1e300, smax = 0.0, cc = 0.0, col[3][3];
                 for (int c = 0; c < 3; ++c) {            // column norms of the 3x3 part = the scale factors (T * R * S)
                     double nrm = 0.0;
-                    for (int r = 0; r < 3; ++r) nrm += (double)s.transform.at(c, r) * (double)s.transform.at(c, r);
+                    for (int r = 0; r < 3; ++r) { col[c][r] = (double)s.transform.at(c, r); nrm += col[c][r] * col[c][r]; }
                     nrm = std::sqrt(nrm);
                     smin = nrm < smin ? nrm : smin; smax = nrm > smax ? nrm : smax;
                     cc += (double)s.transform.at(3, c) * (double)s.transform.at(3, c);
@@ -89,7 +90,23 @@ int DevScene::initiate(Scene& scene) {
                 b.qa = std::nextafter((float)(2.0 * Q * cc), inf);
                 b.qb = std::nextafter((float)(2.0 * Q), inf);
                 if (!std::isfinite(b.qa) || !std::isfinite(b.qb)) { b = DevGeomBox{{-inf, inf, -inf, inf, -inf, inf}, 0.f, 0.f}; }
+                else if (smin > 0.0 && (smax - smin) <= 1e-6 * smax) {
+                    // similarity transform (uniform scale, columns orthogonal): the primitive is a world-space sphere
+                    double dev = 0.0;
+                    for (int c0 = 0; c0 < 3; ++c0) for (int c1 = c0 + 1; c1 < 3; ++c1) {
+                        double d = 0.0;
+                        for (int r = 0; r < 3; ++r) d += col[c0][r] * col[c1][r];
+                        dev = std::fabs(d) > dev ? std::fabs(d) : dev;
+                    }
+                    if (dev <= 1e-6 * smax * smax) {
+                        const double Rp = 0.5 * smax * (1.0 + 2e-6) + pad;
+                        DevGeomBox rb{{s.transform.at(3, 0), s.transform.at(3, 1), s.transform.at(3, 2),
+                                       std::nextafter((float)(Rp * Rp), inf), std::nextafter((float)(2.0 * Rp), inf), 0.f}, 0.f, 0.f};
+                        if (std::isfinite(rb.s[3])) { b = rb; round = true; }
+                    }
+                }
             }
+            if (round) gm[i / 32].round |= 1u << (i % 32);
         }
         gb[i] = b;
         DevGeomMask& mk = gm[i / 32];

@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
 // see one type.  Each path keeps its own compacted slot (the RNG key), hit and state, so results are unchanged; only which
 // lane does the work moves (within the block's contiguous NT-path window, so global accesses stay line-coalesced).
 template <int MODE, int NT>
-__global__ void __launch_bounds__(NT) k_shade_binned(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+__global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
                                                       const int* __restrict__ d_n, PtkHits hits, PtkPaths paths,
                                                       const int* __restrict__ valid_a, const int* __restrict__ agg_a,
                                                       int* __restrict__ valid_b, int* __restrict__ agg_b,
