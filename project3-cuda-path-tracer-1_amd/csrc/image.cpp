@@ -53,10 +53,14 @@ bool decode_png(const std::vector<unsigned char>& d, int& W, int& H, std::vector
         pos += 12 + (size_t)len;
     }
     if (W <= 0 || H <= 0) { err = "PNG without IHDR"; return false; }
+    if (W > 65536 || H > 65536) { err = "PNG dimensions out of range"; return false; }
     if (depth != 8 || interlace != 0) { err = "only 8-bit non-interlaced PNG is supported"; return false; }
     int ch;
     switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: err = "bad PNG colour type"; return false; }
     const size_t stride = (size_t)W * ch;
+    // deflate expands by at most ~1032:1: a header that promises more than the IDAT bytes can hold is corrupt (and must not
+    // drive a multi-gigabyte allocation)
+    if ((stride + 1) * (size_t)H > idat.size() * 1032 + 4096) { err = "PNG image data shorter than its header"; return false; }
     std::vector<unsigned char> raw((stride + 1) * (size_t)H);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) { err = "PNG inflate failed"; return false; }
@@ -97,6 +101,8 @@ bool decode_hdr(const std::vector<unsigned char>& d, int& W, int& H, std::vector
     if (!fmt) { err = "unsupported .hdr format"; return false; }
     line(l);
     if (std::sscanf(l.c_str(), "-Y %d +X %d", &H, &W) != 2 || W <= 0 || H <= 0) { err = "unsupported .hdr orientation"; return false; }
+    // every scanline takes at least 4 bytes flat-per-pixel or 4 + 4 x 2 bytes run-length coded
+    if (W > 65536 || H > 65536 || (size_t)H * 8 > d.size() - (pos < d.size() ? pos : d.size()) + 8) { err = "truncated .hdr"; return false; }
     std::vector<unsigned char> scan((size_t)W * 4);
     rgb.resize((size_t)W * H * 3);
     for (int y = 0; y < H; ++y) {

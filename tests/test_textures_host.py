@@ -75,3 +75,34 @@ def test_ptk_atan2_spec(orc):
     ref = np.arctan2(y.astype(np.float64), x.astype(np.float64))
     assert np.abs(out - ref).max() < 6e-7                       # ~2.5 ulp at pi
     assert out[-8] == 0 and out[-7] == np.float32(np.pi) and out[-6] == np.float32(np.pi / 2) and out[-5] == np.float32(-np.pi / 2) and out[-4] == 0
+
+
+def test_corrupt_headers_are_rejected_not_allocated(ptk, tmp_path):
+    """Found by fuzzing the host loaders under ASan/UBSan: an image header that promises far more pixels than the file holds
+    (flipped bytes in IHDR / the .hdr resolution line) and an absurd RES line must be rejected with a message — not drive a
+    multi-gigabyte allocation or a minutes-long loop."""
+    import struct
+    import zlib
+    base = "CAMERA\nRES 8 8\nFOVY 45\nITERATIONS 1\nDEPTH 2\nFILE x\nEYE 0 0 1\nLOOKAT 0 0 0\nUP 0 1 0\n"
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + bytes([10 * y + x for x in range(4) for _ in range(3)]) for y in range(4))
+    for w, h in ((16, 234881040), (61, 1476395053), (70000, 4)):
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+        (tmp_path / "big.png").write_bytes(png)
+        f = tmp_path / "big_png.txt"; f.write_text("MATERIAL a\nTYPE Lambertian\nALBEDO big.png\n\n" + base)
+        with pytest.raises(ptk.PtkError) as e:
+            ptk.Scene(str(f))
+        assert "decode" in str(e.value), (w, h)
+    (tmp_path / "big.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 8\n" + bytes(64))
+    f = tmp_path / "big_hdr.txt"; f.write_text(base + "\nENV big.hdr\n")
+    with pytest.raises(ptk.PtkError) as e:
+        ptk.Scene(str(f))
+    assert "decode" in str(e.value)
+    f = tmp_path / "big_res.txt"; f.write_text(base.replace("RES 8 8", "RES 800000 800000"))
+    with pytest.raises(ptk.PtkError) as e:
+        ptk.Scene(str(f))
+    assert "RES too large" in str(e.value)
+    with pytest.raises(ptk.PtkError):                       # the override path goes through the same check
+        ptk.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(5000, 5000))
