@@ -532,3 +532,25 @@ def test_fixed_cube_lights(ptk, orc, torch_cuda, mode):
     for it in (1, 2, 3, 4):
         o2.pathtrace(m, it, base)
     assert fixed_sum > 2.0 * float(base.sum())          # reference behaviour: darkened (MIS) or black (DIRECT)
+
+
+def test_degenerate_scenes(ptk, orc, torch_cuda, tmp_path):
+    """No primitives at all (every ray misses at bounce 0), a single bounce, and a scene whose only primitive is the light:
+    images and live counts == oracle in every pipeline."""
+    cam = "CAMERA\nRES 40 24\nFOVY 30\nITERATIONS 2\nDEPTH %d\nFILE x\nEYE 0 1 6\nLOOKAT 0 1 0\nUP 0 1 0\n"
+    light = "MATERIAL l\nTYPE Light\nALBEDO 3 2 1\n\nOBJECT s\nsphere\nmaterial l\nTRANS 0 1 0\nROTAT 0 0 0\nSCALE 2 2 2\n\n"
+    cases = {"empty.txt": cam % 4, "light_only.txt": light + cam % 3, "depth1.txt": light + cam % 1}
+    for name, txt in cases.items():
+        f = tmp_path / name; f.write_text(txt)
+        for mode in (0, 1, 2):
+            o = orc.Scene(str(f))
+            ref = np.zeros((o.P, 3), np.float32)
+            lives = [o.pathtrace(mode, it, ref)[1] for it in (1, 2)]
+            for pipeline in (0, 3, 4):
+                s = ptk.Scene(str(f))
+                r = ptk.Renderer(s, mode, pipeline=pipeline)
+                for k, it in enumerate((1, 2)):
+                    r.iterate(it)
+                    assert np.array_equal(r.live_counts()[0], lives[k]), (name, mode, pipeline, it)
+                img = r.image(); r.close()
+                assert np.array_equal(img, ref), (name, mode, pipeline)
