@@ -62,23 +62,69 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cut by the cgroup quota when there is one, and by 16 (the CPU
+    share of a one-GPU box on this pool) when the quota cannot be read."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            tok = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if tok[0] != "max":
+                    quota = int(tok[0]) / int(tok[1])
+            else:
+                q = int(tok[0])
+                if q > 0:
+                    quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    else:
+        n = min(n, 16)
+    return max(1, n)
+
+
 def cpu_baseline(scene_path, res, depth, mode, seconds):
+    """The CPU restatement (oracle/, kind "port") timed on this host on a bounded sample of the same workload: single thread (the
+    definition of BASELINE configs[0]; this is `value`), then the same loops over all host cores this process may use (OpenMP over
+    paths inside the intersect and shade loops, ordered serial compaction, identical results) as `all_cores`."""
     import numpy as np
     import oracle_lib as orc
     orc.set_trig_mode(orc.TRIG_PTK)
     o = orc.Scene(scene_path, res=res, depth=depth)
-    img = np.zeros((o.P, 3), np.float32)
-    rays = 0; it = 0
-    t0 = time.perf_counter()
-    while True:
-        it += 1
-        r, _ = o.pathtrace(mode, it, img)
-        rays += r
-        el = time.perf_counter() - t0
-        if el >= seconds or it >= 64:
-            break
-    return {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"{it} iteration(s) of the same workload ({rays} rays) in {el:.1f} s, oracle/pt_oracle.cpp, 1 thread"}
+
+    def timed(budget, threads):
+        orc.set_threads(threads)
+        img = np.zeros((o.P, 3), np.float32)
+        stage = np.zeros(4)
+        rays = 0; it = 0
+        t0 = time.perf_counter()
+        while True:
+            it += 1
+            r, _ = o.pathtrace(mode, it, img, timing=stage)
+            rays += r
+            el = time.perf_counter() - t0
+            if el >= budget or it >= 64:
+                break
+        orc.set_threads(1)
+        return rays, it, el, stage
+
+    rays, it, el, stage = timed(0.6 * seconds, 1)
+    out = {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": f"{it} iteration(s) of the same workload ({rays} rays) in {el:.1f} s, oracle/pt_oracle.cpp, 1 thread",
+           "stage_seconds": {k: round(float(v), 3) for k, v in zip(("generate", "intersect", "shade", "compact"), stage)}}
+    cores = host_cores()
+    if cores > 1 and seconds > 0.5:
+        rays, it, el, _ = timed(0.4 * seconds, cores)
+        out["all_cores"] = {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores,
+                            "sample": f"{it} iteration(s) ({rays} rays) in {el:.1f} s, {cores} OpenMP threads, same results"}
+    return out
 
 
 def measure_kernels(ptk, scene, mode, pipeline, steps):

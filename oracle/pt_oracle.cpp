@@ -537,6 +537,18 @@ static inline int mtbvh_offset(v3 dir, int bvh_size) {       // pathtrace.cu:242
 
 struct TraverseStats { uint64_t nodes = 0, tris = 0; };
 static TraverseStats g_stats;
+// Optional multi-threading of the per-path loops (bench.py's all-cores CPU baseline): paths are independent inside the
+// intersect and shade loops (own RNG key, own pixel), compaction stays serial and ordered, so results are identical.
+static int g_threads = 1;
+// traversal counters are accumulated per thread and folded into g_stats at the end of each loop (stats_fold)
+static thread_local TraverseStats t_stats;
+static inline void stats_fold() {
+    if (t_stats.nodes | t_stats.tris) {
+        __atomic_fetch_add(&g_stats.nodes, t_stats.nodes, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_stats.tris, t_stats.tris, __ATOMIC_RELAXED);
+        t_stats = TraverseStats();
+    }
+}
 
 // pathtrace.cu:169-346 computeIntersections body for one path.  Returns rayValid.
 static int intersect_one(const OrcScene& S, const PathSegment& ps, Isect& out) {
@@ -555,13 +567,13 @@ static int intersect_one(const OrcScene& S, const PathSegment& ps, Isect& out) {
     const BvhNode* cur = S.bvh.data() + mtbvh_offset(ray.direction, S.bvh_size);
     int idx = 0; float tempT = FLT_MAX;
     while (idx != -1) {
-        g_stats.nodes++;
+        t_stats.nodes++;
         if (!aabbIntersectP(cur[idx].pMin, cur[idx].pMax, ray, tempT) || tempT > t_min) { idx = cur[idx].miss; continue; }
         if (cur[idx].end - cur[idx].start <= MAX_PRIM) {
             for (int i = cur[idx].start; i < cur[idx].end; ++i) {
                 const Triangle& T = S.triangles[i];
                 float u, v;
-                g_stats.tris++;
+                t_stats.tris++;
                 bool isHit = triIntersect(T, ray, t, u, v);
                 if (isHit && t_min > t) {
                     t_min = t; hit_geom = T.geomIdx; triId = i;
@@ -715,7 +727,7 @@ struct ScatterRec { v3 bsdf; float pdf = 0; v3 dir; };
 
 // the devTexSampler::linearSample(uv) calls of material.h: a bound texture, else the constant
 static const OrcScene* g_tex_scene = nullptr;      // scene whose textures the samplers refer to (set by the entry points)
-static v2 g_uv;                                    // intersection.texCoords of the hit being shaded
+static thread_local v2 g_uv;                       // intersection.texCoords of the hit being shaded
 static inline bool has_tex(int id) { return g_tex_scene && id >= 0 && id < (int)g_tex_scene->textures.size(); }
 static inline float mat_rough(const Material& m) {
     float r = has_tex(m.roughnessMapID) ? linearSample(g_tex_scene->textures[m.roughnessMapID], g_uv).x : m.rough_s;
@@ -1430,6 +1442,7 @@ static void setDevData(OrcScene& S) {
 extern "C" {
 
 void orc_set_trig_mode(int m) { g_trig_mode = m; }
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 void orc_set_light_fix(int on) { g_light_fix = on ? 1 : 0; }
 int orc_get_trig_mode() { return g_trig_mode; }
 
@@ -1568,12 +1581,17 @@ void orc_intersect_env(OrcScene* S, int n, const void* paths, void* isects, int*
     const PathSegment* p = (const PathSegment*)paths; Isect* is = (Isect*)isects;
     g_tex_scene = S;
     const bool env = img && S->envMapID >= 0 && S->envMapID < (int)S->textures.size();
-    for (int i = 0; i < n; ++i) {
-        valid[i] = intersect_one(*S, p[i], is[i]);
-        if (!valid[i] && env) {
-            v3 c = processNAN(p[i].color * linearSample(S->textures[S->envMapID], sphere2Plane(p[i].d)));
-            float* px = radiance_px(img, p[i].pixelIndex); px[0] += c.x; px[1] += c.y; px[2] += c.z;
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
+#pragma omp for schedule(dynamic, 2048)
+        for (int i = 0; i < n; ++i) {
+            valid[i] = intersect_one(*S, p[i], is[i]);
+            if (!valid[i] && env) {
+                v3 c = processNAN(p[i].color * linearSample(S->textures[S->envMapID], sphere2Plane(p[i].d)));
+                float* px = radiance_px(img, p[i].pixelIndex); px[0] += c.x; px[1] += c.y; px[2] += c.z;
+            }
         }
+        stats_fold();
     }
 }
 void orc_intersect(OrcScene* S, int n, const void* paths, void* isects, int* valid) { orc_intersect_env(S, n, paths, isects, valid, nullptr); }
@@ -1581,6 +1599,7 @@ void orc_intersect(OrcScene* S, int n, const void* paths, void* isects, int* val
 void orc_shade(OrcScene* S, int mode, int iter, int depth, int n, const void* isects, void* paths, int* valid, float* img) {
     PathSegment* p = (PathSegment*)paths; const Isect* is = (const Isect*)isects;
     g_tex_scene = S;
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(g_threads) if (g_threads > 1)
     for (int i = 0; i < n; ++i) {
         if (mode == MODE_BSDF) valid[i] = shade_bsdf(*S, iter, i, depth, is[i], p[i], img);
         else if (mode == MODE_MIS) valid[i] = shade_mis(*S, iter, i, depth, is[i], p[i], img);
@@ -1649,7 +1668,7 @@ long long orc_pathtrace_tiled(OrcScene* S, int mode, int iter, int n_parts, int 
 long long orc_pathtrace(OrcScene* S, int mode, int iter, float* img, int* live, double* timing) {
     return orc_pathtrace_tiled(S, mode, iter, 1, 0, 1, img, live, timing);
 }
-void orc_stats(unsigned long long* out, int reset) { out[0] = g_stats.nodes; out[1] = g_stats.tris; if (reset) g_stats = TraverseStats(); }
+void orc_stats(unsigned long long* out, int reset) { stats_fold(); out[0] = g_stats.nodes; out[1] = g_stats.tris; if (reset) g_stats = TraverseStats(); }
 
 // sendImageToPBO (pathtrace.cu:32-65): img sum -> uchar4 (w = 0)
 void orc_tonemap(const float* img, int P, int iter, unsigned char* pbo) {

@@ -71,10 +71,16 @@ L.orc_stats.argtypes = [vp, ci]
 L.orc_tonemap.argtypes = [vp, ci, ci, vp]
 L.orc_set_trig_mode.argtypes = [ci]
 L.orc_set_light_fix.argtypes = [ci]
+L.orc_set_threads.argtypes = [ci]
 
 
 def set_trig_mode(m):
     L.orc_set_trig_mode(m)
+
+
+def set_threads(n):
+    """threads of the per-path loops (results are identical for any count)"""
+    L.orc_set_threads(int(n))
 
 
 def set_light_fix(on):

@@ -114,3 +114,20 @@ def test_fixed_cube_lights_are_consistent(orc):
     assert abs(means[(True, 2)] / means[(True, 0)] - 1) < 0.03, means
     assert means[(False, 2)] < 0.5 * means[(False, 0)], means
     assert means[(False, 0)] == means[(True, 0)]          # BSDF mode never samples lights
+
+
+def test_threaded_oracle_is_identical(orc):
+    """The optional OpenMP threading of the oracle's per-path loops (bench.py's all-cores CPU baseline) changes nothing: image,
+    live counts and traversal counters == the single-thread run."""
+    res = {}
+    for th in (1, 4):
+        orc.set_threads(th)
+        try:
+            S = orc.Scene(os.path.join(ROOT, "scenes", "bunny_cornell.txt"), res=(96, 96), depth=5)
+            img = np.zeros((S.P, 3), np.float32)
+            orc.traversal_stats(reset=True)
+            lives = [S.pathtrace(2, it, img)[1].tolist() for it in (1, 2)]
+            res[th] = (img, lives, orc.traversal_stats(reset=True))
+        finally:
+            orc.set_threads(1)
+    assert np.array_equal(res[1][0], res[4][0]) and res[1][1] == res[4][1] and tuple(res[1][2]) == tuple(res[4][2])
