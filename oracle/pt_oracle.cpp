@@ -1190,19 +1190,29 @@ static int loadMaterial(OrcScene& S, std::istream& in, const std::string& name) 
         if (tk[0] == "TYPE") {
             static const char* names[5] = {"Lambertian", "MetallicWorkflow", "Dielectric", "Microfacet", "Light"};
             for (int k = 0; k < 5; ++k) if (tk.size() > 1 && tk[1] == names[k]) m.type = k;
-        } else if (tk[0] == "ALBEDO") {
-            m.albedoMapID = loadTextureRef(S, tk[1]);
-            if (m.albedoMapID < 0) for (int k = 0; k < 3; ++k) { m.albedo[k] = (float)atof(tk[1 + k].c_str()); m.albedo_s[k] = m.albedo[k]; }
-        } else if (tk[0] == "METALLIC") {
-            m.metallicMapID = loadTextureRef(S, tk[1]);
-            if (m.metallicMapID < 0) m.metal_s = (float)atof(tk[1].c_str());
-        } else if (tk[0] == "ROUGHNESS") {
-            m.roughnessMapID = loadTextureRef(S, tk[1]);
-            if (m.roughnessMapID < 0) { double r = atof(tk[1].c_str()); m.rough_s = (float)(r > ROUGHNESS_MIN ? r : ROUGHNESS_MIN); }   // glm::max(double,double)
-        } else if (tk[0] == "NORMAL") {
-            m.normalMapID = loadTextureRef(S, tk[1]);
-        } else if (tk[0] == "IOR") {
-            m.ior = (float)atof(tk[1].c_str());
+        } else if (tk[0] == "ALBEDO" || tk[0] == "METALLIC" || tk[0] == "ROUGHNESS" || tk[0] == "NORMAL" || tk[0] == "IOR") {
+            // The reference indexes tokens[1] (and [2], [3] for ALBEDO) unconditionally (scene.cpp:268-309): out of bounds on
+            // short lines, e.g. `ALBEDO <missing file>` in camera.txt / normalMap.txt / test.txt / texture_test.txt whose
+            // textures are missing blobs.  Guarded like the product: a keyword without a value is skipped, an ALBEDO that is
+            // neither an existing file nor three numbers is an error.
+            if (tk.size() < 2) continue;
+            if (tk[0] == "ALBEDO") {
+                m.albedoMapID = loadTextureRef(S, tk[1]);
+                if (m.albedoMapID < 0) {
+                    if (tk.size() < 4) { S.error = "ALBEDO needs three numbers: " + line; return -2; }
+                    for (int k = 0; k < 3; ++k) { m.albedo[k] = (float)atof(tk[1 + k].c_str()); m.albedo_s[k] = m.albedo[k]; }
+                }
+            } else if (tk[0] == "METALLIC") {
+                m.metallicMapID = loadTextureRef(S, tk[1]);
+                if (m.metallicMapID < 0) m.metal_s = (float)atof(tk[1].c_str());
+            } else if (tk[0] == "ROUGHNESS") {
+                m.roughnessMapID = loadTextureRef(S, tk[1]);
+                if (m.roughnessMapID < 0) { double r = atof(tk[1].c_str()); m.rough_s = (float)(r > ROUGHNESS_MIN ? r : ROUGHNESS_MIN); }   // glm::max(double,double)
+            } else if (tk[0] == "NORMAL") {
+                m.normalMapID = loadTextureRef(S, tk[1]);
+            } else {
+                m.ior = (float)atof(tk[1].c_str());
+            }
         }
     }
     S.materialNameMap[name] = (int)S.materials.size();
@@ -1225,15 +1235,23 @@ static int loadGeom(OrcScene& S, std::istream& in, const std::string& name) {   
     safeGetline(in, line);
     if (!line.empty() && in.good()) {
         std::vector<std::string> tk = tokenize(line);
-        if (S.materialNameMap.count(tk[1])) g.materialid = S.materialNameMap[tk[1]];
-        else g.materialid = atoi(tk[1].c_str());
+        // the reference indexes tokens[1] unconditionally (scene.cpp:124-131): out of bounds on a one-token line such as the
+        // obsolete-format files' (disney_test.txt).  Guarded here; the id then keeps its initial value.
+        if (tk.size() > 1) {
+            if (S.materialNameMap.count(tk[1])) g.materialid = S.materialNameMap[tk[1]];
+            else g.materialid = atoi(tk[1].c_str());
+        }
     }
+    // the reference never checks the id (a later dev_materials[id] read is then out of bounds); rejected like the product does
+    if (g.materialid < 0 || g.materialid >= (int)S.materials.size()) { S.error = "object " + name + " refers to an unknown material"; return -2; }
     safeGetline(in, line);
     while (!line.empty() && in.good()) {
         std::vector<std::string> tk = tokenize(line);
-        if (tk[0] == "TRANS") tr = v3((float)atof(tk[1].c_str()), (float)atof(tk[2].c_str()), (float)atof(tk[3].c_str()));
-        else if (tk[0] == "ROTAT") rot = v3((float)atof(tk[1].c_str()), (float)atof(tk[2].c_str()), (float)atof(tk[3].c_str()));
-        else if (tk[0] == "SCALE") sc = v3((float)atof(tk[1].c_str()), (float)atof(tk[2].c_str()), (float)atof(tk[3].c_str()));
+        if (tk.size() >= 4) {                     // same guard: the reference reads tokens[1..3] unconditionally
+            if (tk[0] == "TRANS") tr = v3((float)atof(tk[1].c_str()), (float)atof(tk[2].c_str()), (float)atof(tk[3].c_str()));
+            else if (tk[0] == "ROTAT") rot = v3((float)atof(tk[1].c_str()), (float)atof(tk[2].c_str()), (float)atof(tk[3].c_str()));
+            else if (tk[0] == "SCALE") sc = v3((float)atof(tk[1].c_str()), (float)atof(tk[2].c_str()), (float)atof(tk[3].c_str()));
+        }
         safeGetline(in, line);
     }
     g.transform = buildTransformationMatrix(tr, rot, sc);
@@ -1462,8 +1480,8 @@ OrcScene* orc_scene_load(const char* file, int res_w, int res_h, int depth) {
         std::vector<std::string> tk = tokenize(line);
         if (tk.empty()) continue;
         int rc = 1;
-        if (tk[0] == "MATERIAL") rc = loadMaterial(*S, in, tk[1]);
-        else if (tk[0] == "OBJECT") rc = loadGeom(*S, in, tk[1]);
+        if (tk[0] == "MATERIAL" && tk.size() > 1) rc = loadMaterial(*S, in, tk[1]);       // tokens[1] is read unconditionally in the reference
+        else if (tk[0] == "OBJECT" && tk.size() > 1) rc = loadGeom(*S, in, tk[1]);
         else if (tk[0] == "CAMERA") rc = loadCamera(*S, in);
         else if (tk[0] == "ENV" && tk.size() > 1) S->envMapID = loadTextureRef(*S, tk[1]);
         if (rc == -2) return S;
