@@ -45,6 +45,7 @@ CASES = [  # scene, res, depth, mode
     ("cornell.txt", (96, 96), 3, "DIRECT"),
     ("mis_test.txt", (192, 192), 8, "MIS"),          # sphere lights: NEE + shadow rays + lightPDF
     ("mis_test.txt", (128, 128), 4, "DIRECT"),
+    ("mis_test2.txt", (160, 160), 8, "MIS"),         # the reference's second MIS scene, verbatim
     ("metallic_analytic.txt", (128, 128), 8, "MIS"),  # MetallicWorkflow + Dielectric + Microfacet + Lambertian
     ("metallic_analytic.txt", (128, 128), 8, "BSDF"),
     ("bunny_cornell.txt", (128, 128), 5, "BSDF"),     # threaded-BVH traversal, 10 000 triangles

@@ -12,6 +12,7 @@ SCENE_CASES = [
     ("mis_test.txt", (1024, 1024), 16),       # BASELINE config 3
     ("bunny_cornell.txt", None, -1),          # BASELINE config 2 timed scene (10 000 triangles)
     ("metallic_analytic.txt", None, -1),
+    ("mis_test2.txt", None, -1),
 ]
 
 
