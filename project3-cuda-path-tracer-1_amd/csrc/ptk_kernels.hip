@@ -253,7 +253,7 @@ static inline size_t stage_bytes(const SceneView& S) { return S.lds_geoms > 0 ? 
 #define PTK_VALID_TRI 2          // flag value between k_traverse and k_finalize: "closest hit is a triangle, record pending"
 
 template <bool STATS, bool SPLIT>
-__global__ void __launch_bounds__(PTK_BLOCK, 5) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
+__global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
                                                           unsigned long long* ray_total, unsigned long long* stats,
                                                           int* __restrict__ heavy_flag, int* __restrict__ heavy_agg, Gather G) {
