@@ -297,6 +297,32 @@ def test_tonemap(ptk, orc, torch_cuda):
     assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1          # powf: device libm vs glibc
 
 
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_pathtrace_fills_the_pbo(ptk, orc, torch_cuda, lanes):
+    """pathtrace(pbo, frame, iteration) with a device pbo (the viewer's call, main.cpp:212-219): after every call the pbo holds the
+    display transform of the running sum divided by the iteration number (sendImageToPBO, pathtrace.cu:806), also when several
+    iterations are in flight (the planes are summed first).  +-1 LSB for powf; the radiance itself is compared exactly."""
+    torch = torch_cuda
+    name, res, depth = "cornell.txt", (64, 48), 4
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes)
+    pbo = torch.zeros((o.P, 4), dtype=torch.uint8, device="cuda")
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    for it in (1, 2, 3, 4, 5):
+        r.iterate(it, pbo=pbo)
+        o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+        ref_img = planes[0].copy()
+        for p in planes[1:]:
+            ref_img = ref_img + p
+        r.sync()
+        assert np.array_equal(r.image(), ref_img), (lanes, it)
+        ref = np.zeros((o.P, 4), np.uint8); orc.L.orc_tonemap(ref_img.ctypes.data, o.P, it, ref.ctypes.data)
+        got = pbo.cpu().numpy()
+        assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1, (lanes, it)
+    r.close()
+
+
 def test_tile_partition(ptk, orc, torch_cuda):
     """Multi-GPU sharding: each part renders its interleaved row tiles; every part equals the oracle run with
     the same partition, parts are disjoint, and the summed image is a valid full-frame render (same live pixels)."""
