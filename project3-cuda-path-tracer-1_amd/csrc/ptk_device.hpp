@@ -253,6 +253,13 @@ struct GeomXf { float inv[12], fwd[12]; int diag; };
 #define PTK_XF_FLOATS 24
 #define PTK_LDS_GEOMS_MAX 512          // 48 KB of LDS; larger scenes use the wave-uniform loops
 struct GeomStage { const float* xf; bool on; };
+// the same record by reference: the exact tests read inv / fwd from LDS where they use them (fwd only on a hit), which keeps
+// 12-24 registers free compared with the by-value copy
+struct GeomXfRef { const float* inv; const float* fwd; int diag; };
+PTK_DI GeomXfRef ref_xf(const float* xf, int i, int diag) {
+    GeomXfRef g; g.inv = xf + (size_t)i * PTK_XF_FLOATS; g.fwd = g.inv + 12; g.diag = diag;
+    return g;
+}
 PTK_DI GeomXf load_xf(const float* xf, int i, int diag) {
     GeomXf g;
     const float* p = xf + (size_t)i * PTK_XF_FLOATS;
@@ -518,7 +525,7 @@ PTK_DI void analytic_closest(const SceneView& S, const GeomStage& gs, f3 ro, f3 
         while (mc) {
             const int k = __builtin_ctz(mc), i = base + k;
             mc &= mc - 1u;
-            const GeomXf g = load_xf(gs.xf, i, (c.diag >> k) & 1);
+            const GeomXfRef g = ref_xf(gs.xf, i, (c.diag >> k) & 1);
             f3 tp, tn;
             const float t = box_test(g, ro, rd, tp, tn);
             if (t > 0.0f && (a.t_min > t || (a.t_min == t && i < a.geom))) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
@@ -526,7 +533,7 @@ PTK_DI void analytic_closest(const SceneView& S, const GeomStage& gs, f3 ro, f3 
         while (ms) {
             const int k = __builtin_ctz(ms), i = base + k;
             ms &= ms - 1u;
-            const GeomXf g = load_xf(gs.xf, i, (c.diag >> k) & 1);
+            const GeomXfRef g = ref_xf(gs.xf, i, (c.diag >> k) & 1);
             f3 tp, tn;
             const float t = sphere_test(g, ro, rd, tp, tn);
             if (t > 0.0f && (a.t_min > t || (a.t_min == t && i < a.geom))) { a.t_min = t; a.geom = i; a.P = tp; a.NS = tn; }
@@ -644,7 +651,7 @@ PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3
             while (mc) {
                 const int k = __builtin_ctz(mc);
                 mc &= mc - 1u;
-                const GeomXf g = load_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
                 f3 tp, tn;
                 const float t = box_test(g, ori, dir, tp, tn);
                 if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;
@@ -652,7 +659,7 @@ PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3
             while (ms) {
                 const int k = __builtin_ctz(ms);
                 ms &= ms - 1u;
-                const GeomXf g = load_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
                 f3 tp, tn;
                 const float t = sphere_test(g, ori, dir, tp, tn);
                 if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) return true;

@@ -157,7 +157,7 @@ __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const
                     r = (int)(e & ((1u << RB) - 1u));
                     const int k = (int)(e >> RB);
                     const float4 o4 = s_ray[2 * r], d4 = s_ray[2 * r + 1];
-                    const GeomXf g = load_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                    const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
                     const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
                     const float t = pi < Tc ? box_test(g, po, pd, P, NSv) : sphere_test(g, po, pd, P, NSv);
                     if (t > 0.0f && FLT_MAX > t) {
