@@ -227,17 +227,36 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
 
 // Replay path: the launches of one iteration are captured once per lane into a hipGraph whose kernels read the iteration
 // number from L.iter_dev (stepped by n_lanes at the end of every replay), so a replay needs no argument patching.
+// returns 0, a launch error of the captured kernels (> 0 or PTK_E_*), or -1000 when the graph machinery itself failed
+int build_graph(Lane& L, int iter, int mode) {
+    hipError_t e;
+    if (L.graph_exec) { (void)hipGraphExecDestroy(L.graph_exec); L.graph_exec = nullptr; }
+    if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; }
+    if ((e = hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return -1000;
+    const int rc = enqueue_iteration(L, iter, mode, true);
+    e = hipStreamEndCapture(L.stream, &L.graph);
+    if (rc) { if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; } return rc; }
+    if (e != hipSuccess || !L.graph) { L.graph = nullptr; return -1000; }
+    if ((e = hipGraphInstantiate(&L.graph_exec, L.graph, nullptr, nullptr, 0)) != hipSuccess) {
+        (void)hipGraphDestroy(L.graph); L.graph = nullptr; L.graph_exec = nullptr;
+        return -1000;
+    }
+    return 0;
+}
+
 int replay_iteration(Lane& L, int iter, int mode) {
     hipError_t e;
     if (!L.graph_exec || L.graph_mode != mode) {
-        if (L.graph_exec) { (void)hipGraphExecDestroy(L.graph_exec); L.graph_exec = nullptr; }
-        if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; }
-        if ((e = hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return (int)e;
-        int rc = enqueue_iteration(L, iter, mode, true);
-        e = hipStreamEndCapture(L.stream, &L.graph);
+        const int rc = build_graph(L, iter, mode);
+        if (rc == -1000) {
+            // capture / instantiate refused by the runtime: same kernels, launched one by one (identical results)
+            (void)hipGetLastError();
+            std::fprintf(stderr, "ptk: hipGraph capture failed, falling back to eager launches\n");
+            g.use_graph = false;
+            L.expected_iter = -1;
+            return enqueue_iteration(L, iter, mode, false);
+        }
         if (rc) return rc;
-        if (e != hipSuccess) return (int)e;
-        if ((e = hipGraphInstantiate(&L.graph_exec, L.graph, nullptr, nullptr, 0)) != hipSuccess) return (int)e;
         L.graph_mode = mode;
         L.expected_iter = -1;
     }
