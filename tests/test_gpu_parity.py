@@ -566,7 +566,8 @@ def test_degenerate_scenes(ptk, orc, torch_cuda, tmp_path):
     images and live counts == oracle in every pipeline."""
     cam = "CAMERA\nRES 40 24\nFOVY 30\nITERATIONS 2\nDEPTH %d\nFILE x\nEYE 0 1 6\nLOOKAT 0 1 0\nUP 0 1 0\n"
     light = "MATERIAL l\nTYPE Light\nALBEDO 3 2 1\n\nOBJECT s\nsphere\nmaterial l\nTRANS 0 1 0\nROTAT 0 0 0\nSCALE 2 2 2\n\n"
-    cases = {"empty.txt": cam % 4, "light_only.txt": light + cam % 3, "depth1.txt": light + cam % 1}
+    flat = "MATERIAL d\nTYPE Lambertian\nALBEDO .7 .7 .7\n\nOBJECT flat\ncube\nmaterial d\nTRANS 0 0 0\nROTAT 10 20 30\nSCALE 4 0 4\n\n"      # singular transform
+    cases = {"empty.txt": cam % 4, "light_only.txt": light + cam % 3, "depth1.txt": light + cam % 1, "scale0.txt": light + flat + cam % 3}
     for name, txt in cases.items():
         f = tmp_path / name; f.write_text(txt)
         for mode in (0, 1, 2):
