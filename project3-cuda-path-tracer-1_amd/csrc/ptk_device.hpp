@@ -1,7 +1,8 @@
 // ptk_device.hpp — device-side math of the path-tracing hot path for gfx950 (wave64).
 //
 // Scalar-per-lane code: one path per lane, scene constants addressed with wave-uniform
-// indices so the compiler keeps them in SGPRs (s_load), per-lane state in VGPRs.
+// indices so the compiler keeps them in SGPRs (s_load), per-lane state in VGPRs; records a
+// lane picks for itself (its candidate primitive, its material) are read from LDS copies.
 //
 // NUMERICS CONTRACT.  This file is compiled with -ffp-contract=off and the default
 // correctly-rounded fp32 divide/sqrt.  Every expression is written in the evaluation order
@@ -16,7 +17,11 @@
 //   * triangle attributes are interpolated once for the final closest hit instead of at
 //     every accepted candidate (pure function of triangle, u, v);
 //   * next-event estimation towards a cube light is skipped: in the reference it always
-//     evaluates to 0 or NaN->0 (lightSample.h:171-248 assigns no position/pdf for cubes).
+//     evaluates to 0 or NaN->0 (lightSample.h:171-248 assigns no position/pdf for cubes),
+//     unless the opt-in fix (SceneView::light_fix) is on;
+//   * analytic primitives that provably miss are not tested (analytic_candidates), and the
+//     closest one is chosen by "smaller t, then smaller index" — the winner of the
+//     reference's first-found-wins loop in index order, for any visiting order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
