@@ -339,10 +339,18 @@ static inline float sample1D(Rng& r) {
     return res * (1.f - 0.f) + 0.f;
 }
 // utilities.h:54-56  sample2D = glm::vec2(sample1D(s), sample1D(s)).  C++ leaves the evaluation order of the two
-// constructor arguments unspecified.  The SURVEY [probe] records (g++ host build of the reference) show the SECOND
-// argument drawn first (y = 1st draw, x = 2nd draw); the oracle follows that order so that it stays pinned to them.
-// (What nvcc emits for the device build cannot be observed here; both orders are statistically equivalent.)
-static inline v2 sample2D(Rng& r) { v2 o; o.y = sample1D(r); o.x = sample1D(r); return o; }
+// constructor arguments unspecified, and the two builds of the reference differ:
+//  * nvcc device code (what the reference actually renders with) draws the FIRST argument first (x = 1st draw).  Settled
+//    against the reference's own renders gallery/{Direct,MIS,BSDF}20.png: with x first, every one of the 20 iterations of
+//    each image reproduces the gallery noise pixel for pixel (tests/golden/make_gallery_fixture.py, tests/test_gallery.py);
+//    with y first none does.  This is the DEFAULT (g_s2d_xfirst = 1) and what the HIP kernels implement.
+//  * the g++ host build the SURVEY [probe] records came from draws the SECOND argument first; orc_set_sample2d_order(0)
+//    selects that order so the oracle stays checkable against those records (tests/test_oracle_pins.py).
+// g_dbg_slot_shift is an analysis knob of the gallery test only: it offsets the compacted slot in the shading RNG key
+// (the reference's GPU build flips a few sphere-silhouette hits per iteration, which shifts every later slot).
+static int g_dbg_slot_shift = 0;
+static int g_s2d_xfirst = 1;
+static inline v2 sample2D(Rng& r) { v2 o; if (g_s2d_xfirst) { o.x = sample1D(r); o.y = sample1D(r); } else { o.y = sample1D(r); o.x = sample1D(r); } return o; }
 
 // ---------------------------------------------------------------------------------------
 // scene-side PODs (interchange layouts, dword-for-dword what the tests exchange)
@@ -1005,7 +1013,7 @@ static int shade_bsdf(const OrcScene& S, int iter, int idx, int depth, const Ise
     int valid = 0;
     const Material& m = S.materials[is.materialId];
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
-    Rng rng = make_rng(iter, idx, depth);
+    Rng rng = make_rng(iter, idx + g_dbg_slot_shift, depth);
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     if (srec.pdf == 0) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
@@ -1027,7 +1035,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
     const Material& m = S.materials[is.materialId];
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
     bool isDelta = (m.type == MAT_DIELECTRIC);
-    Rng rng = make_rng(iter, idx, depth);
+    Rng rng = make_rng(iter, idx + g_dbg_slot_shift, depth);
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     v3 viewPos = is.p, viewNor = is.n;
@@ -1063,7 +1071,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
 
 // pathtrace.cu:348-403 DirectLiPTkernel, one path (always rayValid = 0)
 static int shade_direct(const OrcScene& S, int iter, int idx, int depth, const Isect& is, PathSegment& ps, float* img) {
-    Rng rng = make_rng(iter, idx, depth);
+    Rng rng = make_rng(iter, idx + g_dbg_slot_shift, depth);
     const Material& m = S.materials[is.materialId];
     float* px = radiance_px(img, ps.pixelIndex);
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
@@ -1460,6 +1468,8 @@ static void setDevData(OrcScene& S) {
 extern "C" {
 
 void orc_set_trig_mode(int m) { g_trig_mode = m; }
+void orc_set_debug_slot_shift(int k) { g_dbg_slot_shift = k; }
+void orc_set_sample2d_order(int xfirst) { g_s2d_xfirst = xfirst ? 1 : 0; }
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 void orc_set_light_fix(int on) { g_light_fix = on ? 1 : 0; }
 int orc_get_trig_mode() { return g_trig_mode; }

@@ -101,8 +101,10 @@ PTK_DI float sample1D(Rng& r) {
     r.x = x;
     return (float)(x - 1u) / 2147483648.0f;
 }
-// sample2D (utilities.h:54-56): second constructor argument drawn first — see oracle/pt_oracle.cpp sample2D.
-PTK_DI f2 sample2D(Rng& r) { f2 o; o.y = sample1D(r); o.x = sample1D(r); return o; }
+// sample2D (utilities.h:54-56): glm::vec2(sample1D(s), sample1D(s)) — unspecified argument order in C++; the reference's
+// nvcc device build draws the FIRST argument first, settled against its own 20-spp gallery renders (DESIGN.md §2,
+// tests/test_gallery.py).
+PTK_DI f2 sample2D(Rng& r) { f2 o; o.x = sample1D(r); o.y = sample1D(r); return o; }
 
 // ---- device scene tables ---------------------------------------------------------------------------
 // Analytic primitive, 36 dwords.  Matrices as 3 rows x 4 (row-major) of glm's column-major mat4: m[r*4+c] = M[c][r].

@@ -70,6 +70,8 @@ L.orc_pathtrace_batch.restype = C.c_longlong; L.orc_pathtrace_batch.argtypes = [
 L.orc_stats.argtypes = [vp, ci]
 L.orc_tonemap.argtypes = [vp, ci, ci, vp]
 L.orc_set_trig_mode.argtypes = [ci]
+L.orc_set_sample2d_order.argtypes = [ci]
+L.orc_set_debug_slot_shift.argtypes = [ci]
 L.orc_set_light_fix.argtypes = [ci]
 L.orc_set_threads.argtypes = [ci]
 

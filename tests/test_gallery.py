@@ -1,0 +1,197 @@
+"""Parity against the only outputs the reference itself holds for this path: its six 1080x1080 renders of
+scenes/mis_test2.txt, gallery/{Direct,BSDF,MIS}{20,2000}.png (one per SampleMode, preview.h:13; written by saveImage,
+main.cpp:146-170).  tests/golden/gallery_mis_test2.npz holds their pixels / block means (generator + the meaning of the
+fitted `slot_shift` table: tests/golden/make_gallery_fixture.py).
+
+CPU tier (oracle, libm trig, the reference's nvcc draw order):
+  * with the slot-shift table the oracle reproduces the 20-spp gallery images PIXEL FOR PIXEL on the lit plate pixels:
+    Direct >= 99 %, BSDF >= 99 %, MIS >= 94 % exact (>= 98.5 % within 1 level).  Direct20 is the image the table was fitted
+    on; MIS20 and BSDF20 are out of sample.  Measured: 99.39 / 99.40 / 95.06 % (98.87 % within 1).
+  * with the OTHER sample2D draw order (the g++ host order) the same table matches nothing (< 20 %): this is what settles
+    the draw order.
+  * without the table (what the product renders): statistical agreement of 8x8 block means.
+GPU tier: the HIP path (ptk_pathtrace + ptk_tonemap through the C ABI) at 20 and 2000 spp against the gallery's block
+means / plate pixels with the stated tolerances, and bit-exact against the oracle at 1080x1080 depth 8 in all three modes."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NPZ = os.path.join(ROOT, "tests", "golden", "gallery_mis_test2.npz")
+SCENE = os.path.join(ROOT, "scenes", "mis_test2.txt")
+W = 1080
+R0, R1 = 636, 940
+MODES = {"Direct": 1, "BSDF": 0, "MIS": 2}          # SampleMode values of the C ABI / oracle
+
+
+def _fixture():
+    return np.load(NPZ, allow_pickle=False)
+
+
+def save_transform(img_sum, spp):
+    """main.cpp:146-170 + image.cpp:56-67 in float32: sum/spp, ACESFilm, pow(1/2.2), x-flip, (uchar)(clamp*255)"""
+    x = img_sum.reshape(W, W, 3) / np.float32(spp)
+    a, b, c, d, e = (np.float32(v) for v in (2.51, 0.03, 2.43, 0.59, 0.14))
+    y = np.clip((x * (a * x + b)) / (x * (c * x + d) + e), 0, 1).astype(np.float32)
+    y = np.power(y, np.float32(1 / 2.2)).astype(np.float32)[:, ::-1, :]
+    return (np.clip(y, 0, 1) * np.float32(255)).astype(np.uint8)
+
+
+def block_means(a, b):
+    h, w = a.shape[:2]
+    return a.astype(np.float64).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3)).astype(np.float32)
+
+
+@pytest.fixture()
+def gallery_oracle(orc):
+    orc.L.orc_set_debug_slot_shift.argtypes = [orc.ci]
+    orc.L.orc_set_sample2d_order.argtypes = [orc.ci]
+    orc.set_trig_mode(orc.TRIG_LIBM)
+    orc.set_threads(os.cpu_count() or 1)
+    yield orc
+    orc.L.orc_set_debug_slot_shift(0)
+    orc.L.orc_set_sample2d_order(1)
+    orc.set_threads(1)
+    orc.set_trig_mode(orc.TRIG_PTK)
+
+
+def _render_with_table(orc, mode, table):
+    """20 iterations; iteration `it`, pixel row r rendered with shading slot + table[it, r]; per-pixel sum in iteration order"""
+    s = orc.Scene(SCENE)
+    assert (s.width, s.height, s.trace_depth) == (W, W, 8)
+    acc = np.zeros((W, W, 3), np.float32)
+    for it in range(1, 21):
+        one = np.zeros((W, W, 3), np.float32)
+        for k in np.unique(table[it]):
+            orc.L.orc_set_debug_slot_shift(int(k))
+            img = np.zeros((W * W, 3), np.float32)
+            s.pathtrace(mode, it, img)
+            rows = table[it] == k
+            one[rows] = img.reshape(W, W, 3)[rows]
+        acc += one
+    orc.L.orc_set_debug_slot_shift(0)
+    s.close()
+    return acc
+
+
+def _plate_match(out_u8, g, name):
+    ref = g["rows_" + name].astype(np.int32)
+    d = np.abs(out_u8[R0:R1].astype(np.int32) - ref).max(axis=2)
+    lit = g["lit"] & (ref.sum(axis=2) > 0)
+    return float((d[lit] == 0).mean()), float((d[lit] <= 1).mean()), int(lit.sum())
+
+
+@pytest.mark.parametrize("name,min_exact,min_within1", [("Direct", 0.99, 0.995), ("BSDF", 0.99, 0.994), ("MIS", 0.94, 0.985)])
+def test_oracle_reproduces_gallery_pixels(gallery_oracle, name, min_exact, min_within1):
+    orc = gallery_oracle
+    g = _fixture()
+    acc = _render_with_table(orc, MODES[name], g["slot_shift"].astype(np.int32))
+    out = save_transform(acc, 20)
+    exact, within1, n = _plate_match(out, g, name + "20")
+    print(f"{name}20: {n} lit plate pixels, exact {exact:.4f}, within 1 level {within1:.4f}")
+    assert exact >= min_exact and within1 >= min_within1, (exact, within1)
+    # whole image through 8x8 block means (includes the three lights and the black background)
+    db = np.abs(block_means(out, 8) - g["blocks8_" + name + "20"])
+    assert db.mean() < 0.05 and np.percentile(db, 99.9) < 4.0, (db.mean(), db.max())
+
+
+def test_other_draw_order_matches_nothing(gallery_oracle):
+    """y-first (the g++ host build's order) with the same table: the noise is unrelated to the gallery's"""
+    orc = gallery_oracle
+    g = _fixture()
+    orc.L.orc_set_sample2d_order(0)
+    acc = _render_with_table(orc, MODES["Direct"], g["slot_shift"].astype(np.int32))
+    exact, within1, _ = _plate_match(save_transform(acc, 20), g, "Direct20")
+    print(f"y-first: exact {exact:.4f}, within 1 level {within1:.4f}")
+    assert exact < 0.2
+
+
+@pytest.mark.parametrize("name", ["Direct", "BSDF", "MIS"])
+def test_oracle_unshifted_is_statistically_the_gallery(gallery_oracle, name):
+    """what the product computes (no table): same image up to which silhouette pixels flipped -> different noise, same mean"""
+    orc = gallery_oracle
+    g = _fixture()
+    s = orc.Scene(SCENE)
+    img = np.zeros((W * W, 3), np.float32)
+    for it in range(1, 21):
+        s.pathtrace(MODES[name], it, img)
+    s.close()
+    out = save_transform(img, 20)
+    _check_statistical(out, g, name + "20")
+
+
+# tolerances of the statistical comparison (8-bit levels), per image: (mean |block delta| over lit blocks, global mean delta)
+STAT_TOL = {"Direct20": (3.0, 0.05), "MIS20": (3.0, 0.05), "BSDF20": (12.0, 0.1),     # measured (oracle): 1.15/0.006, 1.00/0.005, 5.56/0.015
+            "Direct2000": (1.2, 0.15), "MIS2000": (1.2, 0.15), "BSDF2000": (2.5, 0.2)}
+
+
+def _check_statistical(out_u8, g, name):
+    ref_b = g["blocks8_" + name]
+    b = block_means(out_u8, 8)
+    lit = ref_b.sum(axis=2) > 3
+    mad = float(np.abs(b - ref_b)[lit].mean())
+    gm = float(np.abs(b.mean(axis=(0, 1)) - ref_b.mean(axis=(0, 1))).max())
+    dark = float(np.abs(b - ref_b)[~lit].max()) if (~lit).any() else 0.0
+    print(f"{name}: lit-block mean |delta| {mad:.3f} levels, global mean delta {gm:.4f}, darkest-region max delta {dark:.3f}")
+    tol_mad, tol_gm = STAT_TOL[name]
+    assert mad < tol_mad and gm < tol_gm, (name, mad, gm)
+    return mad, gm
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU tier
+# ------------------------------------------------------------------------------------------------------------------
+def _gpu_render(ptk, mode, iters, **kw):
+    import torch
+    s = ptk.Scene(SCENE)
+    assert (s.width, s.height, s.trace_depth) == (W, W, 8)
+    r = ptk.Renderer(s, mode, **kw)
+    for it in range(1, iters + 1):
+        r.iterate(it)
+    img = r.image()
+    dev = torch.from_numpy(img).cuda()
+    pbo = torch.zeros((W * W, 4), dtype=torch.uint8, device="cuda")
+    ptk.tonemap(dev, W, W, iters, pbo)                              # sendImageToPBO's transform (pathtrace.cu:32-65), on the device
+    torch.cuda.synchronize()
+    out = pbo.cpu().numpy().reshape(W, W, 4)[:, ::-1, :3]            # saveImage's x-flip
+    r.close(); s.close()
+    return img, np.ascontiguousarray(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Direct", "BSDF", "MIS"])
+def test_gpu_gallery_20spp(ptk, orc, name):
+    g = _fixture()
+    img, out = _gpu_render(ptk, MODES[name], 20)
+    _check_statistical(out, g, name + "20")
+    # device tonemap == saveImage's host transform within 1 level (powf)
+    host = save_transform(img, 20)
+    assert np.abs(host.astype(np.int32) - out.astype(np.int32)).max() <= 1
+    # and the radiance itself is the oracle's, bit for bit (ptk trig), at the gallery's own size
+    orc.set_trig_mode(orc.TRIG_PTK); orc.set_threads(os.cpu_count() or 1)
+    try:
+        s = orc.Scene(SCENE)
+        ref = np.zeros((W * W, 3), np.float32)
+        for it in range(1, 21):
+            s.pathtrace(MODES[name], it, ref)
+        s.close()
+    finally:
+        orc.set_threads(1)
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Direct", "BSDF", "MIS"])
+def test_gpu_gallery_2000spp(ptk, name):
+    """converged renders: the HIP path against the reference's 2000-spp images (different silhouette flips -> different
+    noise realisation, so the comparison is statistical: block means, and plate pixels through 4x4 means)"""
+    g = _fixture()
+    img, out = _gpu_render(ptk, MODES[name], 2000, in_flight=3, graph=True)
+    _check_statistical(out, g, name + "2000")
+    p4 = block_means(out[R0:R1], 4)
+    d = np.abs(p4 - g["plate4_" + name + "2000"])
+    lit = g["plate4_" + name + "2000"].sum(axis=2) > 3
+    frac2 = float((d[lit].max(axis=1) <= 2.0).mean())
+    print(f"{name}2000: 4x4 plate blocks within 2 levels: {frac2:.4f}; mean |delta| {d[lit].mean():.3f}")
+    assert frac2 > (0.80 if name == "BSDF" else 0.97), frac2

@@ -15,8 +15,13 @@ PROBES = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_probes.jso
 
 @pytest.fixture(autouse=True)
 def _libm_trig(orc):
+    """the SURVEY probes come from a g++ host build of the reference: glibc sinf/cosf and g++'s sample2D argument order
+    (second argument drawn first).  The oracle's default order is the reference's nvcc order (tests/test_gallery.py)."""
+    orc.L.orc_set_sample2d_order.argtypes = [orc.ci]
     orc.set_trig_mode(orc.TRIG_LIBM)
+    orc.L.orc_set_sample2d_order(0)
     yield
+    orc.L.orc_set_sample2d_order(1)
     orc.set_trig_mode(orc.TRIG_PTK)
 
 
