@@ -113,6 +113,11 @@ int  ptk_scene_get_materials(const PtkScene* s, PtkMaterial* out);
 int  ptk_scene_get_triangles(const PtkScene* s, PtkTriangle* out);
 int  ptk_scene_get_bvh(const PtkScene* s, PtkBvhNode* out);          /* 6 * bvh_size nodes */
 int  ptk_scene_get_lights(const PtkScene* s, PtkLight* out);
+/* The 8-wide collapsed form of the same BVH (src/BVH.cpp:13-239 builds the binary tree; the collapse and why it is
+ * parity-preserving: csrc/wide_bvh.h).  counts[4] = wide nodes (0: the tree cannot be collapsed, the threaded walk is
+ * used), leaf records, levels, per-ray stack bound.  nodes: 144 B each, leaves: 64 B each (layout: csrc/ptk_device.hpp). */
+int  ptk_scene_wide_bvh_counts(const PtkScene* s, int* counts);
+int  ptk_scene_get_wide_bvh(const PtkScene* s, void* nodes, void* leaves);
 /* Upload the scene tables to the current HIP device (DevScene::initiate, src/scene.cpp:569-663). */
 int  ptk_scene_upload(PtkScene* s);
 

@@ -32,7 +32,7 @@ E_BADARG, E_NOSCENE, E_PARSE, E_NODEVICE = 1001, 1002, 1003, 1004
 ABI_SYMBOLS = [
     "ptk_scene_load", "ptk_scene_free", "ptk_scene_error", "ptk_scene_counts", "ptk_scene_get_camera",
     "ptk_scene_get_geoms", "ptk_scene_get_materials", "ptk_scene_get_triangles", "ptk_scene_get_bvh",
-    "ptk_scene_get_lights", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
+    "ptk_scene_get_lights", "ptk_scene_wide_bvh_counts", "ptk_scene_get_wide_bvh", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
     "ptk_shade", "ptk_tonemap", "ptk_pathtrace_init", "ptk_pathtrace_free", "ptk_pathtrace",
     "ptk_set_sample_mode", "ptk_get_sample_mode", "ptk_get_image", "ptk_get_image_device",
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
@@ -76,6 +76,7 @@ GEOM_DT = np.dtype([("type", "<i4"), ("materialid", "<i4"), ("transform", "<f4",
 MATERIAL_DT = np.dtype([("type", "<i4"), ("albedo", "<f4", 3), ("albedo_s", "<f4", 3), ("rough_s", "<f4"), ("metal_s", "<f4"), ("ior", "<f4"),
                         ("albedoMapID", "<i4"), ("metallicMapID", "<i4"), ("roughnessMapID", "<i4"), ("normalMapID", "<i4")])
 TRIANGLE_DT = np.dtype([("v", "<f4", 9), ("n", "<f4", 9), ("tex", "<f4", 6), ("tangent", "<f4", 3), ("bitangent", "<f4", 3), ("geomIdx", "<i4")])
+WIDE_LEAF_DT = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("tri", "<i4")])
 BVHNODE_DT = np.dtype([("pMin", "<f4", 3), ("pMax", "<f4", 3), ("start", "<i4"), ("end", "<i4"), ("miss", "<i4"), ("hit", "<i4")])
 LIGHT_DT = np.dtype([("geomID", "<i4"), ("triangleID", "<i4"), ("type", "<i4")])
 CAMERA_DT = np.dtype([("res", "<i4", 2), ("position", "<f4", 3), ("lookAt", "<f4", 3), ("view", "<f4", 3), ("up", "<f4", 3),
@@ -109,6 +110,8 @@ def _load() -> C.CDLL:
     for name in ("counts", "get_camera", "get_geoms", "get_materials", "get_triangles", "get_bvh", "get_lights"):
         getattr(lib, "ptk_scene_" + name).argtypes = [vp, vp]
     lib.ptk_scene_upload.argtypes = [vp]
+    lib.ptk_scene_wide_bvh_counts.argtypes = [vp, vp]
+    lib.ptk_scene_get_wide_bvh.argtypes = [vp, vp, vp]
     lib.ptk_scene_get_texture_size.argtypes = [vp, ci, vp, vp]
     lib.ptk_scene_get_texture.argtypes = [vp, ci, vp]
     lib.ptk_generate_rays.argtypes = [C.POINTER(PtkCamera), ci, ci, PtkPaths, vp]
@@ -179,6 +182,15 @@ class Scene:
     def triangles(self): return self._table(lib.ptk_scene_get_triangles, TRIANGLE_DT, self.n_triangles)
     def bvh(self): return self._table(lib.ptk_scene_get_bvh, BVHNODE_DT, 6 * self.bvh_size)
     def lights(self): return self._table(lib.ptk_scene_get_lights, LIGHT_DT, self.n_lights)
+
+    def wide_bvh(self):
+        """-> (nodes uint32 [n, 36], leaves (WIDE_LEAF_DT) [m], depth, stack bound) of the 8-wide collapsed tree; n = 0 if there is none"""
+        c = np.zeros(4, np.int32)
+        _chk(lib.ptk_scene_wide_bvh_counts(self.handle, c.ctypes.data), "ptk_scene_wide_bvh_counts")
+        nodes = np.zeros((int(c[0]), 36), np.uint32); leaves = np.zeros(int(c[1]), WIDE_LEAF_DT)
+        if c[0] > 0:
+            _chk(lib.ptk_scene_get_wide_bvh(self.handle, nodes.ctypes.data, leaves.ctypes.data), "ptk_scene_get_wide_bvh")
+        return nodes, leaves, int(c[2]), int(c[3])
 
     def texture(self, i: int) -> np.ndarray:
         """float32 [h, w, 3], row 0 = bottom row (as the reference loads it)"""

@@ -11,6 +11,7 @@
 //   DevTriA[T]       64 B each : vertex normals, texcoords, geomIdx (touched once per ray, for the final hit)
 #include "ptk_internal.h"
 #include "image.h"
+#include "wide_bvh.h"
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -173,6 +174,15 @@ int DevScene::initiate(Scene& scene) {
     if ((rc = upload(&dev_materials, m))) return rc;
     if ((rc = upload(&dev_nodes, nodes))) return rc;
     if ((rc = upload(&dev_trie, te))) return rc;
+    wide_nodes = wide_depth = wide_stack = 0;
+    if (!scene.triangles.empty()) {                          // 8-wide collapsed form of the same tree (wide_bvh.h)
+        WideBvh wb;
+        if (build_wide_bvh(scene.gpuBVHNodes, B, scene.triangles, wb)) {
+            if ((rc = upload(&dev_wnodes, wb.nodes))) return rc;
+            if ((rc = upload(&dev_wleaves, wb.leaves))) return rc;
+            wide_nodes = (int)wb.nodes.size(); wide_depth = wb.depth; wide_stack = wb.max_stack;
+        }
+    }
     if ((rc = upload(&dev_triv, tv))) return rc;
     if ((rc = upload(&dev_tria, ta))) return rc;
     if ((rc = upload(&dev_lights, li))) return rc;
@@ -185,8 +195,9 @@ int DevScene::initiate(Scene& scene) {
 }
 
 void DevScene::destroy() {
-    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_trie, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
+    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_trie, &dev_wnodes, &dev_wleaves, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    wide_nodes = 0;
     uploaded = false;
 }
 
@@ -294,6 +305,24 @@ int ptk_scene_get_bvh(const PtkScene* s, PtkBvhNode* o) {
         o[i].pMax[0] = n.pMax.x; o[i].pMax[1] = n.pMax.y; o[i].pMax[2] = n.pMax.z;
         o[i].start = n.start; o[i].end = n.end; o[i].miss = n.miss; o[i].hit = n.hit;
     }
+    return 0;
+}
+
+int ptk_scene_wide_bvh_counts(const PtkScene* s, int* c) {
+    if (!s || !s->scene || !c) return PTK_E_BADARG;
+    c[0] = c[1] = c[2] = c[3] = 0;
+    WideBvh wb;
+    if (!s->scene->triangles.empty() && build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb)) {
+        c[0] = (int)wb.nodes.size(); c[1] = (int)wb.leaves.size(); c[2] = wb.depth; c[3] = wb.max_stack;
+    }
+    return 0;
+}
+int ptk_scene_get_wide_bvh(const PtkScene* s, void* nodes, void* leaves) {
+    if (!s || !s->scene || !nodes || !leaves) return PTK_E_BADARG;
+    WideBvh wb;
+    if (s->scene->triangles.empty() || !build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb)) return PTK_E_BADARG;
+    std::memcpy(nodes, wb.nodes.data(), wb.nodes.size() * sizeof(WideNodeHost));
+    std::memcpy(leaves, wb.leaves.data(), wb.leaves.size() * sizeof(WideLeafHost));
     return 0;
 }
 

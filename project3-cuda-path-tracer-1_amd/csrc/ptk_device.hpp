@@ -153,6 +153,18 @@ struct DevNode {
     float minx, miny, minz, maxx, maxy, maxz;
     int a, b;
 };
+// 8-wide collapsed node of the SAME binary tree (host builder + the parity argument: wide_bvh.h), 144 B = 9 x uint4:
+//   q[0]     = {p.x, p.y, p.z, ex | ey << 8 | ez << 16 | n << 24}   quantisation origin, biased exponents of the per-axis
+//                                                                    scale 2^(e-127), number of children n (1..8)
+//   q[1 + c] = child c: {qlo.x | qlo.y << 8 | qlo.z << 16 | qhi.x << 24,
+//                        qhi.y | qhi.z << 8 | before[0] << 16 | before[1] << 24,
+//                        before[2] | before[3] << 8 | before[4] << 16 | before[5] << 24,
+//                        ref}
+//              the child spans [p + qlo * 2^e, p + qhi * 2^e] (a superset of its exact box; unused slots are inverted);
+//              before[d] = mask of the children a ray of direction tree d (pathtrace.cu:242-244) visits before this one;
+//              ref = wide-node index, or 0x80000000 | leaf-record index.
+// Leaf record, 64 B = 4 x uint4: exact fp32 box of the reference's leaf node, the triangle in edge form (as DevTriE), its index.
+struct WideLeaf { float lo[3], hi[3], v0[3], e1[3], e2[3]; int tri; };
 struct DevTriE { float v0[3], e1[3], e2[3], pad[3]; };                          // 48 B: v0 and the two edges (e = v - v0 as in Bounds3.hpp:300-301)
 struct DevTriV { float v0[3], v1[3], v2[3]; };                                  // 36 B, positions (attribute interpolation, light sampling)
 struct DevTriA { float n0[3], n1[3], n2[3]; float t0[2], t1[2], t2[2]; int geomIdx; float tangent[3]; };  // 76 B, shading attributes
@@ -167,6 +179,8 @@ struct SceneView {
     const DevMaterial* mats;     int n_mats;
     const DevNode* nodes;        int bvh_size;   // [6][bvh_size]
     const DevTriE* trie;         // traversal form of the triangles
+    const uint4* wnodes;         int n_wnodes;   // 8-wide collapsed form of the same tree (WideNode, 6 x uint4 each); null = none
+    const uint4* wleaves;        // WideLeaf records (4 x uint4 each), children of one wide node consecutive
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;
     const DevTex* tex;           const float* texels;   int env_tex;     // env_tex = envMapID (-1: none)

@@ -12,6 +12,11 @@ struct PtkScene {
 
 namespace ptk {
 
+// BVH walk of the work-list rays (both give bit-identical hits): the reference's threaded walk, one ray per lane (fewest
+// instructions: best when several iterations in flight fill the machine); four lanes per ray over the 8-wide collapsed tree
+// (shortest dependent chain: best with one iteration in flight).  AUTO picks by the number of iterations in flight.
+enum { PTK_WALK_AUTO = 0, PTK_WALK_THREADED = 1, PTK_WALK_WIDE = 2 };
+
 void set_light_fix(bool on);            // opt-in fixed cube lights (ptk_set_light_fix)
 bool light_fix_enabled();
 void set_uniform_analytic(bool on);     // A/B: disable the staged candidate loops (ptk_set_pipeline(2))
@@ -27,6 +32,8 @@ inline SceneView dev_view(const ::Scene& s) {
     d.mats = (const DevMaterial*)t.dev_materials; d.n_mats = (int)s.materials.size();
     d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
     d.trie = (const DevTriE*)t.dev_trie;
+    d.wnodes = (const uint4*)t.dev_wnodes;       d.n_wnodes = t.wide_nodes;
+    d.wleaves = (const uint4*)t.dev_wleaves;
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
     d.tex = (const DevTex*)t.dev_textures;       d.texels = (const float*)t.dev_texture_data; d.env_tex = t.envMapID;
@@ -57,6 +64,7 @@ struct Workspace {               // per-render-context scratch, device memory
     int* srcidx = nullptr; int* seg_pref = nullptr; int* seg_first = nullptr;
     bool segmented = true;       // false: k_scatter moves the survivors (pipeline 4)
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
+    int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)
     int capacity = 0;
 };
 

@@ -367,6 +367,159 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_traverse_wide: the same walk over the 8-wide collapsed form of the same tree (wide_bvh.h has the parity argument:
+// only leaf visits have effects, inner tests only prune, so any conservative pruning + the reference's leaf order gives
+// bit-identical winners).
+//
+// FOUR LANES PER RAY (a "quad"; 16 rays per wave64, 64 per block).  The work list of a bounce holds ~150 k rays on a
+// machine with 524 k lane slots: with one ray per lane the walk runs at ~2 waves per SIMD and its time is the dependent
+// chain of the slowest lane (measured: one-lane-per-ray over this same tree 185 us per launch, the threaded walk 125 us).
+// A quad shortens the chain and quadruples the waves: lane q of a quad owns children q and q + 4 of the node, so a visit is
+// 3 independent 16-B loads per lane (header + two child records, no dependent loads) and two child tests instead of eight.
+//   * child test: t = q * (2^e / d) + (p - o) / d — one v_cvt_f32_ubyte + one v_fma per plane — widened by
+//     m = 2^-20 (|(p - o) / d| + 255 |2^e / d|), which bounds every rounding difference against the exact leaf test
+//     t = (plane - o) * (1 / d) (derivation: DESIGN.md section 5);
+//   * two ballots give the quad its 8-bit hit mask; a hit child's position among the hit children in the ray's visiting
+//     order is popc(hits & before[dir]) (the node stores, per direction tree, which children precede each child), so all
+//     hit children are pushed at once, in reverse visiting order, without a loop;
+//   * per-ray stack in LDS; the first PTK_WIDE_TOP nodes of the breadth-first node array (the top 3-4 levels) are staged
+//     in LDS once per block;
+//   * leaves run the reference's exact box test, the `tEnter > t_min` cut and the Moeller-Trumbore test (same functions
+//     as the threaded walk), redundantly in the four lanes.
+// Rays with a zero / denormal direction component (Bounds3.hpp:174-177 containment tests) and rays whose stack would
+// overflow take the threaded walk instead — same result by construction.
+// ------------------------------------------------------------------------------------------------------------------
+#define PTK_WIDE_TOP 128          // wide nodes staged in LDS (18 KB)
+#define PTK_WIDE_STACK 24         // stack entries per ray
+#define PTK_WIDE_STRIDE 25        // odd: the 16 rays of a wave spread over the LDS banks
+#define PTK_WIDE_RAYS (PTK_BLOCK / 4)
+#define PTK_WIDE_LEAF 0x80000000u
+
+struct WideRay { f3 o, d, inv; float t_min; int tri; float u, v; int dir; };
+
+// conservative test of one child record against the ray (see above); A/Bn/Bf are per visit, per axis
+struct WideFrame { float Ax, Ay, Az, Bnx, Bny, Bnz, Bfx, Bfy, Bfz; bool px, py, pz; };
+__device__ __forceinline__ bool wide_child_test(const uint4 c, const WideFrame& f, float t_min) {
+    const float lox = (float)(c.x & 0xffu), loy = (float)((c.x >> 8) & 0xffu), loz = (float)((c.x >> 16) & 0xffu);
+    const float hix = (float)(c.x >> 24), hiy = (float)(c.y & 0xffu), hiz = (float)((c.y >> 8) & 0xffu);
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(f.px ? lox : hix, f.Ax, f.Bnx), __builtin_fmaf(f.py ? loy : hiy, f.Ay, f.Bny)),
+                           __builtin_fmaf(f.pz ? loz : hiz, f.Az, f.Bnz));
+    const float tf = fminf(fminf(__builtin_fmaf(f.px ? hix : lox, f.Ax, f.Bfx), __builtin_fmaf(f.py ? hiy : loy, f.Ay, f.Bfy)),
+                           __builtin_fmaf(f.pz ? hiz : loz, f.Az, f.Bfz));
+    return tn <= fminf(tf, t_min) && tf >= 0.f;
+}
+__device__ __forceinline__ unsigned wide_before(const uint4 c, int dir) {      // before[dir] of a child record
+    const unsigned long long w = ((unsigned long long)c.z << 32) | c.y;
+    return (unsigned)(w >> (16 + 8 * dir)) & 0xffu;
+}
+
+// exact leaf visit (walk_apply's leaf branch on the leaf's own box): pathtrace.cu:249-267
+__device__ __forceinline__ int wide_leaf_visit(const uint4 l0, const uint4 l1, const uint4 l2, const uint4 l3, WideRay& r) {
+    DevNode nd;
+    nd.minx = __uint_as_float(l0.x); nd.miny = __uint_as_float(l0.y); nd.minz = __uint_as_float(l0.z);
+    nd.maxx = __uint_as_float(l0.w); nd.maxy = __uint_as_float(l1.x); nd.maxz = __uint_as_float(l1.y);
+    nd.a = 0; nd.b = 0;
+    float tEnter;
+    if (!aabb_test_fast(nd, r.o, r.inv, tEnter) || tEnter > r.t_min) return 0;
+    DevTriE T;
+    T.v0[0] = __uint_as_float(l1.z); T.v0[1] = __uint_as_float(l1.w); T.v0[2] = __uint_as_float(l2.x);
+    T.e1[0] = __uint_as_float(l2.y); T.e1[1] = __uint_as_float(l2.z); T.e1[2] = __uint_as_float(l2.w);
+    T.e2[0] = __uint_as_float(l3.x); T.e2[1] = __uint_as_float(l3.y); T.e2[2] = __uint_as_float(l3.z);
+    float tt, u, v;
+    if (tri_test(T, r.o, r.d, tt, u, v) && r.t_min > tt) { r.t_min = tt; r.tri = (int)l3.w; r.u = u; r.v = v; }
+    return 1;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
+                                                              PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
+                                                              const int* __restrict__ srcidx) {
+    __shared__ uint4 s_top[PTK_WIDE_TOP * 9];
+    __shared__ unsigned s_stack[PTK_WIDE_RAYS * PTK_WIDE_STRIDE];
+    const int m = (int)*list_count;
+    if (blockIdx.x * PTK_WIDE_RAYS >= m) return;
+    const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
+    for (int k = threadIdx.x; k < n_top * 9; k += PTK_BLOCK) s_top[k] = S.wnodes[k];
+    __syncthreads();
+    const int q = threadIdx.x & 3;                               // lane within the quad
+    const int qsh = (threadIdx.x & 63) & ~3;                     // first lane of the quad within the wave
+    const int j = blockIdx.x * PTK_WIDE_RAYS + (threadIdx.x >> 2);
+    unsigned nv = 0, nt = 0;
+    if (j < m) {
+        const int ray = list[j];
+        const int src = srcidx ? srcidx[ray] : ray;
+        const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
+        const float t0 = hits.t_n[4 * (size_t)ray];
+        WideRay r;
+        r.o = mk3(o4.x, o4.y, o4.z); r.d = mk3(d4.x, d4.y, d4.z);
+        r.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        r.t_min = t0 > 0.f ? t0 : FLT_MAX; r.tri = -1; r.u = 0.f; r.v = 0.f;
+        r.dir = mtbvh_dir(r.d);
+        const float t_init = r.t_min;
+        // the fast slab test needs finite non-zero 1/d (Bounds3.hpp:174-177 otherwise); |d_k| >= 1e-30 keeps 2^e / d finite
+        bool threaded = !(fabsf(r.d.x) >= 1e-30f && fabsf(r.d.y) >= 1e-30f && fabsf(r.d.z) >= 1e-30f);
+        if (!threaded) {
+            unsigned* stk = s_stack + (threadIdx.x >> 2) * PTK_WIDE_STRIDE;
+            WideFrame f;
+            f.px = r.inv.x > 0.f; f.py = r.inv.y > 0.f; f.pz = r.inv.z > 0.f;
+            int sp = 0;
+            unsigned cur = 0u;                                   // root
+            for (;;) {
+                if (!(cur & PTK_WIDE_LEAF)) {
+                    uint4 q0, ca, cb;
+                    if ((int)cur < n_top) { const uint4* np = s_top + cur * 9; q0 = np[0]; ca = np[1 + q]; cb = np[5 + q]; asm volatile("" : "+v"(q0.x), "+v"(ca.x), "+v"(cb.x)); }
+                    else { const uint4* np = S.wnodes + (size_t)cur * 9; q0 = np[0]; ca = np[1 + q]; cb = np[5 + q]; asm volatile("" : "+v"(q0.x), "+v"(ca.x), "+v"(cb.x)); }
+                    if (STATS) nv += (q == 0);
+                    const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+                    f.Ax = sx * r.inv.x; f.Ay = sy * r.inv.y; f.Az = sz * r.inv.z;                     // exact (power-of-two scale)
+                    const float Bx = (__uint_as_float(q0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(q0.y) - r.o.y) * r.inv.y, Bz = (__uint_as_float(q0.z) - r.o.z) * r.inv.z;
+                    const float K = 9.5367431640625e-07f;                                              // 2^-20
+                    const float mx = K * (fabsf(Bx) + 255.f * fabsf(f.Ax)) + 1e-36f, my = K * (fabsf(By) + 255.f * fabsf(f.Ay)) + 1e-36f, mz = K * (fabsf(Bz) + 255.f * fabsf(f.Az)) + 1e-36f;
+                    f.Bnx = Bx - mx; f.Bfx = Bx + mx; f.Bny = By - my; f.Bfy = By + my; f.Bnz = Bz - mz; f.Bfz = Bz + mz;
+                    const int nc = (int)(q0.w >> 24);
+                    const bool ha = (q < nc) & wide_child_test(ca, f, r.t_min);       // no short circuit: straight-line code
+                    const bool hb = (q + 4 < nc) & wide_child_test(cb, f, r.t_min);
+                    const unsigned long long b0 = __ballot(ha), b1 = __ballot(hb);
+                    const unsigned H = ((unsigned)(b0 >> qsh) & 15u) | (((unsigned)(b1 >> qsh) & 15u) << 4);    // hit children of this ray
+                    const int nh = __popc(H);
+                    if (sp + nh > PTK_WIDE_STACK) { threaded = true; break; }
+                    // all hit children at once, in reverse visiting order: the child visited first ends on top
+                    if (ha) stk[sp + nh - 1 - __popc(H & wide_before(ca, r.dir))] = ca.w;
+                    if (hb) stk[sp + nh - 1 - __popc(H & wide_before(cb, r.dir))] = cb.w;
+                    sp += nh;
+                } else {
+                    const uint4* lp = S.wleaves + (size_t)(cur & ~PTK_WIDE_LEAF) * 4;
+                    const uint4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
+                    (void)wide_leaf_visit(l0, l1, l2, l3, r);
+                    if (STATS) nt += (q == 0);
+                }
+                if (sp == 0) break;
+                --sp; cur = stk[sp];
+            }
+        }
+        if (threaded) {                                          // the reference's own walk (also the overflow fallback)
+            Walk w;
+            walk_begin(S, r.o, r.d, t_init, w);
+            while (w.idx != -1) {
+                const int k = walk_step(S, w);
+                if (STATS && q == 0) { nv++; nt += k; }
+            }
+            r.tri = w.tri; r.u = w.u; r.v = w.v; r.t_min = w.t_min;
+        }
+        if (q == 0 && r.tri >= 0) {
+            st4(hits.uv_ids, ray, make_float4(r.u, r.v, r.t_min, __int_as_float(r.tri)));
+            valid[ray] = PTK_VALID_TRI;
+        }
+    }
+    if (STATS && stats) {
+        unsigned long long a = nv, c = nt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
+    }
+}
+
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits,
                                                          int* __restrict__ valid, int* __restrict__ agg) {
     const int n = d_n ? *d_n : n_arg;
@@ -1084,7 +1237,7 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
-                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G) {
+                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
@@ -1100,7 +1253,11 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
+    const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
+    if (wide && stats && wide_stats) k_traverse_wide<true><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    else if (wide && !stats) k_traverse_wide<false><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg);
@@ -1126,7 +1283,7 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
     if (seg && depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
     // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
-                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G);
+                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk);
     if (rc) return rc;
     if (S.env_tex >= 0) {
         k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride, G.src);

@@ -1,0 +1,174 @@
+// wide_bvh.cpp — collapses the reference's binary SAH tree (as threaded by BVH.cpp:180-239) into 8-wide quantised nodes.
+// See wide_bvh.h for why the result is bit-identical to the reference's walk.
+#include "wide_bvh.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+
+namespace ptk {
+
+namespace {
+
+struct Topo {
+    const std::vector<GpuBVHNode>& mt;
+    int B;
+    bool leaf(int i) const { return mt[i].end - mt[i].start <= 1; }
+    int left(int i) const { return i + 1; }
+    int right(int i) const { return i + 2 * (mt[i + 1].end - mt[i + 1].start); }     // a subtree over n leaves has 2n - 1 nodes
+    int near_child(int d, int i) const { return mt[(size_t)d * B + i].hit; }
+    double area(int i) const {
+        const GpuBVHNode& n = mt[i];
+        const double x = (double)n.pMax.x - n.pMin.x, y = (double)n.pMax.y - n.pMin.y, z = (double)n.pMax.z - n.pMin.z;
+        return x * y + y * z + z * x;
+    }
+};
+
+bool check_topology(const Topo& T) {
+    if (T.B <= 0 || (int)T.mt.size() != 6 * T.B) return false;
+    for (int i = 0; i < T.B; ++i) {
+        const GpuBVHNode& n = T.mt[i];
+        if (n.end - n.start < 1) return false;                       // empty leaves only exist in triangle-free scenes
+        if (T.leaf(i)) continue;
+        const int L = T.left(i), R = T.right(i);
+        if (L >= T.B || R >= T.B || R <= L) return false;
+        if (T.mt[L].start != n.start || T.mt[L].end != T.mt[R].start || T.mt[R].end != n.end) return false;
+        for (int d = 0; d < 6; ++d) { const int h = T.near_child(d, i); if (h != L && h != R) return false; }
+        for (int d = 1; d < 6; ++d) {                                // same boxes in every copy
+            const GpuBVHNode& c = T.mt[(size_t)d * T.B + i];
+            if (std::memcmp(&c.pMin, &n.pMin, sizeof(n.pMin)) || std::memcmp(&c.pMax, &n.pMax, sizeof(n.pMax))) return false;
+        }
+    }
+    return true;
+}
+
+// depth-first order of the frontier slots below binary node `i`, near child first (direction d)
+void order_slots(const Topo& T, int d, int i, const std::vector<int>& slot_of, std::vector<int>& out) {
+    if (slot_of[i] >= 0) { out.push_back(slot_of[i]); return; }
+    const int L = T.left(i), R = T.right(i), nr = T.near_child(d, i);
+    order_slots(T, d, nr, slot_of, out);
+    order_slots(T, d, nr == L ? R : L, slot_of, out);
+}
+
+float comp(const vec3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+} // namespace
+
+bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<Triangle>& tris, WideBvh& out) {
+    out = WideBvh();
+    Topo T{mt, B};
+    if (tris.empty() || !check_topology(T)) return false;
+    struct Pending { int root; int level; };
+    std::deque<Pending> queue;
+    queue.push_back({0, 0});
+    std::vector<int> slot_of(B, -1);
+    std::vector<int> node_root;                      // binary root of every wide node (for the stack bound)
+    std::vector<std::vector<int>> kids;              // inner children (wide indices) per wide node
+    std::vector<int> nkids;
+    size_t next_index = 1;                           // wide index the next enqueued node will get
+    while (!queue.empty()) {
+        const Pending cur = queue.front(); queue.pop_front();
+        const int r = cur.root;
+        out.depth = std::max(out.depth, cur.level + 1);
+        std::vector<int> fr;
+        if (T.leaf(r)) fr.push_back(r);
+        else {
+            fr.push_back(T.left(r)); fr.push_back(T.right(r));
+            while (fr.size() < 8) {
+                int best = -1; double ba = -1.0;
+                for (size_t k = 0; k < fr.size(); ++k) if (!T.leaf(fr[k]) && T.area(fr[k]) > ba) { ba = T.area(fr[k]); best = (int)k; }
+                if (best < 0) break;
+                const int f = fr[best];
+                fr[best] = T.left(f);
+                fr.insert(fr.begin() + best + 1, T.right(f));
+            }
+        }
+        const int n = (int)fr.size();
+        WideNodeHost nd; std::memset(&nd, 0, sizeof(nd));
+        const GpuBVHNode& box = mt[r];
+        uint32_t imask = 0;
+        for (int c = 0; c < n; ++c) if (!T.leaf(fr[c])) imask |= 1u << c;
+        // quantisation frame: origin = box.pMin, per-axis scale 2^e with p + 255 * 2^e >= box.pMax
+        uint32_t eb[3];
+        uint8_t qlo[3][8], qhi[3][8];
+        for (int a = 0; a < 3; ++a) {
+            const long double p = comp(box.pMin, a), hi = comp(box.pMax, a);
+            if (!std::isfinite((double)p) || !std::isfinite((double)hi)) return false;
+            int e = -126;
+            const long double ext = hi - p;
+            if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2((double)(ext / 255.0L))) - 1);
+            while (p + 255.0L * std::ldexp(1.0L, e) < hi) ++e;
+            if (e > 60) return false;                                 // absurd extents: scale * (1 / d) could overflow on the device
+            eb[a] = (uint32_t)(e + 127);
+            const long double s = std::ldexp(1.0L, e);
+            for (int c = 0; c < 8; ++c) { qlo[a][c] = 255; qhi[a][c] = 0; }
+            for (int c = 0; c < n; ++c) {
+                const long double lo_c = comp(mt[fr[c]].pMin, a), hi_c = comp(mt[fr[c]].pMax, a);
+                long double ql = std::floor((lo_c - p) / s), qh = std::ceil((hi_c - p) / s);
+                ql = std::min(255.0L, std::max(0.0L, ql)); qh = std::min(255.0L, std::max(0.0L, qh));
+                while (ql > 0 && p + ql * s > lo_c) ql -= 1;
+                while (qh < 255 && p + qh * s < hi_c) qh += 1;
+                if (p + ql * s > lo_c || p + qh * s < hi_c) return false;
+                qlo[a][c] = (uint8_t)ql; qhi[a][c] = (uint8_t)qh;
+            }
+        }
+        float pf[3] = {box.pMin.x, box.pMin.y, box.pMin.z};
+        std::memcpy(&nd.w[0], pf, 12);
+        nd.w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)n << 24);
+        // children: inner ones become consecutive wide nodes (breadth-first), leaves consecutive leaf records (slot order)
+        uint32_t ref[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<int> my_kids;
+        for (int c = 0; c < n; ++c) {
+            if (imask & (1u << c)) { queue.push_back({fr[c], cur.level + 1}); my_kids.push_back((int)next_index); ref[c] = (uint32_t)next_index; ++next_index; }
+            else {
+                const GpuBVHNode& lf = mt[fr[c]];
+                if (lf.start < 0 || lf.start >= (int)tris.size()) return false;
+                const Triangle& t = tris[lf.start];
+                WideLeafHost L;
+                L.lo[0] = lf.pMin.x; L.lo[1] = lf.pMin.y; L.lo[2] = lf.pMin.z;
+                L.hi[0] = lf.pMax.x; L.hi[1] = lf.pMax.y; L.hi[2] = lf.pMax.z;
+                const vec3* v = t.v;                                   // same fp32 subtractions as DevTriE (Bounds3.hpp:300-301)
+                L.v0[0] = v[0].x; L.v0[1] = v[0].y; L.v0[2] = v[0].z;
+                L.e1[0] = v[1].x - v[0].x; L.e1[1] = v[1].y - v[0].y; L.e1[2] = v[1].z - v[0].z;
+                L.e2[0] = v[2].x - v[0].x; L.e2[1] = v[2].y - v[0].y; L.e2[2] = v[2].z - v[0].z;
+                L.tri = lf.start;
+                ref[c] = 0x80000000u | (uint32_t)out.leaves.size();
+                out.leaves.push_back(L);
+            }
+        }
+        // visiting order per direction -> before[d][c]: the children visited before child c by a ray of direction tree d
+        uint32_t before[6][8];
+        for (int c = 0; c < n; ++c) slot_of[fr[c]] = c;
+        for (int d = 0; d < 6; ++d) {
+            std::vector<int> ord;
+            order_slots(T, d, r, slot_of, ord);
+            if ((int)ord.size() != n) return false;
+            uint32_t seen = 0;
+            for (int k = 0; k < n; ++k) { before[d][ord[k]] = seen; seen |= 1u << ord[k]; }
+            for (int c = n; c < 8; ++c) before[d][c] = 0;
+        }
+        for (int c = 0; c < n; ++c) slot_of[fr[c]] = -1;
+        for (int c = 0; c < 8; ++c) {
+            uint32_t* w = &nd.w[4 + 4 * c];
+            w[0] = (uint32_t)qlo[0][c] | ((uint32_t)qlo[1][c] << 8) | ((uint32_t)qlo[2][c] << 16) | ((uint32_t)qhi[0][c] << 24);
+            w[1] = (uint32_t)qhi[1][c] | ((uint32_t)qhi[2][c] << 8) | (before[0][c] << 16) | (before[1][c] << 24);
+            w[2] = before[2][c] | (before[3][c] << 8) | (before[4][c] << 16) | (before[5][c] << 24);
+            w[3] = ref[c];
+        }
+        out.nodes.push_back(nd);
+        kids.push_back(my_kids); nkids.push_back(n);
+    }
+    if (out.leaves.size() != tris.size() || out.nodes.size() != next_index) return false;
+    // per-ray stack bound: a visit pushes at most (children - 1) entries and descends into one
+    std::vector<int> need(out.nodes.size(), 0);
+    for (int i = (int)out.nodes.size() - 1; i >= 0; --i) {
+        int below = 0;
+        for (int k : kids[i]) below = std::max(below, need[k]);
+        need[i] = (nkids[i] - 1) + below;
+    }
+    out.max_stack = need.empty() ? 0 : need[0];
+    out.ok = true;
+    return true;
+}
+
+} // namespace ptk

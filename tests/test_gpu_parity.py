@@ -174,11 +174,12 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3, 4])
+@pytest.mark.parametrize("pipeline", [1, 2, 3, 4, 5, 6])
 def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
     """ptk_set_pipeline variants (1 = staged kernels with the BVH walked inside the intersect kernel, 2 = the same with wave-uniform
     loops over every analytic primitive instead of the staged candidate loops, 3 = the fused bounce kernel with chained scans,
-    4 = staged intersect + shading that compacts its survivors through one chained scan)
+    4 = staged intersect + shading that compacts its survivors through one chained scan, 5 = default pipeline with the work-list
+    rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree with four lanes per ray)
     produce exactly the oracle's results."""
     for name, res, depth, mode in (("bunny_cornell.txt", (128, 128), 5, "MIS"), ("obj_test.txt", (64, 64), 4, "BSDF"), ("cornell.txt", (96, 96), 4, "BSDF")):
         m = MODES[mode]
@@ -193,6 +194,26 @@ def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
             assert np.array_equal(counts, live), (name, it)
         img = r.image(); r.close()
         assert np.array_equal(img, ref), name
+
+
+@pytest.mark.parametrize("name,mode", [("bunny_cornell.txt", "BSDF"), ("bunny_cornell.txt", "MIS"), ("obj_test.txt", "MIS")])
+def test_wide_walk_equals_threaded_walk_full_size(ptk, torch_cuda, name, mode):
+    """BASELINE configs[2] size (800x800 depth 8): the walk over the 8-wide collapsed tree (pipeline 6) and the reference's
+    threaded walk (pipeline 5) give the same radiance and live counts bit for bit, with one and with three iterations in
+    flight (the default picks between them by that number); the oracle comparison at this size is test_full_size_configs."""
+    out = {}
+    for pipeline in (5, 6):
+        for lanes in (1, 3):
+            s = ptk.Scene(os.path.join(SC, name))
+            r = ptk.Renderer(s, MODES[mode], pipeline=pipeline, in_flight=lanes, graph=lanes > 1)
+            lives = []
+            for it in (1, 2, 3):
+                r.iterate(it); lives.append(r.live_counts()[0].copy())
+            out[(pipeline, lanes)] = (r.image(), np.stack(lives))
+            r.close(); s.close()
+    for lanes in (1, 3):
+        assert np.array_equal(out[(5, lanes)][1], out[(6, lanes)][1])
+        assert np.array_equal(out[(5, lanes)][0], out[(6, lanes)][0]), int((out[(5, lanes)][0] != out[(6, lanes)][0]).any(axis=1).sum())
 
 
 def test_intersect_edge_rays(ptk, orc, torch_cuda):
