@@ -153,12 +153,15 @@ def measure_kernels(ptk, scene, mode, pipeline, steps):
     return prof, rays, counts, nodes, tris, rays_s
 
 
-def pmc_traffic(scene_file):
-    """HBM bytes per k_intersect launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, one
-    counter per pass; profiles/r1_pmc_traffic.json says how they were taken).  PMC collection cannot run inside this process."""
+PMC_FILE = "profiles/r2_pmc.json"
+
+
+def pmc_record(scene_file):
+    """Committed rocprofv3 PMC passes of the intersect stage (profiles/r2_pmc.json says how they were taken: separate --pmc
+    passes with --kernel-trace only; FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md).  PMC collection cannot run inside
+    this process, so the numbers are read from the committed summary."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["scenes"].get(scene_file)
-        return d["traffic_bytes_per_launch"] if d else None
+        return json.load(open(os.path.join(ROOT, PMC_FILE)))["scenes"].get(scene_file)
     except Exception:
         return None
 
@@ -169,13 +172,21 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
     bytes_per_ray = BYTES_PER_RAY_ANALYTIC + ((BYTES_PER_NODE * nodes + BYTES_PER_TRI * tris) / max(rays_s, 1) if has_bvh else 0.0)
     achieved = rays_p * bytes_per_ray / (ms_int * 1e-3) / 1e9 if ms_int > 0 else 0.0
     live_launches = max(int((counts > 0).sum()), 1)          # launches per iteration that had paths to process
+    pmc = pmc_record(scene_file) if (scene.width, scene.height) == (800, 800) else None
+    traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+    avg_us = 1e3 * ms_int / (steps * live_launches)
+    hbm = {"achieved_hbm": round(traffic / (avg_us * 1e-6) / 1e9, 1), "frac_hbm": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+           "achieved_hbm_note": "PMC traffic / this run's average launch time: the rate the HBM really sees (node / triangle re-reads of a "
+                                "BVH scene are served by L2); `achieved` is the ALGORITHMIC rate at the reference's struct sizes (SURVEY 8d)"} if traffic else {}
     return {
-        "bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(scene_file) if (scene.width, scene.height) == (800, 800) else None,
-        "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r1_pmc_traffic.json)",
+        "bound": "hbm", "kernel": "k_intersect" + (" + k_list + k_traverse_wide + k_finalize (the intersect stage)" if has_bvh else ""),
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE, **hbm,
+        "counters": (pmc or {}).get("counters"),
         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_p / (steps * live_launches)),
         "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / (steps * live_launches), 1),
-        "avg_launch_us": round(1e3 * ms_int / (steps * live_launches), 2),
+        "avg_launch_us": round(avg_us, 2),
         "nodes_per_ray": round(nodes / max(rays_s, 1), 3) if has_bvh else 0, "tris_per_ray": round(tris / max(rays_s, 1), 3) if has_bvh else 0,
         "note": "algorithmic bytes (SURVEY 8d) x rays / device time of k_intersect, HIP events on the render stream, %d untimed "
                 "iterations on one stream; launches with zero live paths excluded from the average; per-kernel ms/iter: %s" % (
@@ -255,6 +266,39 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
         q = torch.tensor([rays], dtype=torch.int64, device=dev); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
 
+    multi = None
+    if N > 1:
+        # the other scaling mode and the collective alone, measured after the headline (every rank takes part)
+        other_spp = 1 if weak else N
+        r2 = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), spp=other_spp)
+        r_saved, r = r, r2
+        for i in range(1, a.warmup + 1):
+            r.iterate(i)
+        barrier(); q0 = r.ray_total(); barrier()
+        tt0 = time.perf_counter()
+        for i in range(a.warmup + 1, a.warmup + 1 + a.steps):
+            r.iterate(i)
+        reduce_radiance()
+        barrier()
+        tt = time.perf_counter() - tt0
+        q = r.ray_total() - q0
+        t_red0 = time.perf_counter()
+        for _ in range(5):
+            reduce_radiance()
+        barrier()
+        t_red = (time.perf_counter() - t_red0) / 5
+        r.close(); r = r_saved
+        dev = "cuda" if a.backend == "nccl" else "cpu"
+        t = torch.tensor([tt, t_red], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        qq = torch.tensor([q], dtype=torch.int64, device=dev); dist.all_reduce(qq, op=dist.ReduceOp.SUM)
+        this = {"value": round(rays / elapsed / 1e6, 3), "samples_per_launch": spp}
+        that = {"value": round(int(qq.item()) / float(t[0].item()) / 1e6, 3), "samples_per_launch": other_spp}
+        multi = {"weak": this if weak else that, "strong": that if weak else this, "unit": "Mrays/s",
+                 "reduce_ms": round(1e3 * float(t[1].item()), 4),
+                 "reduce_note": "one dist.reduce(SUM) of the float32[3*W*H] radiance buffer to rank 0 (+ the device copy into the "
+                                "send buffer), mean of 5, max over ranks; it is inside both timed regions once",
+                 "note": "weak: every rank traces N samples of its tiles per launch (per-GPU work fixed); strong: one sample per "
+                         "launch (whole-frame work fixed, per-rank launches shrink by N)"}
     if rank == 0:
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
         roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)
@@ -274,13 +318,28 @@ def main():
             pb = measure_kernels(ptk, bs, mode, a.pipeline, a.profile_steps)
             extra["roofline_bvh_scene"] = dict(roofline_of(bs, *pb, a.profile_steps, a.bvh_scene), workload=f"scenes/{a.bvh_scene} {bs.width}x{bs.height} depth {bs.trace_depth}",
                                                mrays_per_s=round(brays / bms / 1e3, 1))
+        ref_order = None
+        if N == 1 and (a.in_flight != 1 or a.graph):
+            # the reference's own schedule: one iteration at a time, eager launches -> its float accumulation order exactly
+            # (the headline overlaps `in_flight` iterations: image = ((p0 + p1) + p2), each iteration itself unchanged)
+            rr = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=1, graph=False)
+            for i in range(1, a.warmup + 1):
+                rr.iterate(i)
+            rr.sync(); q0 = rr.ray_total(); tt0 = time.perf_counter()
+            for i in range(a.warmup + 1, a.warmup + 1 + a.steps):
+                rr.iterate(i)
+            rr.sync(); tt = time.perf_counter() - tt0; qr = rr.ray_total() - q0
+            rr.close()
+            ref_order = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(1e3 * tt / a.steps, 4),
+                         "config": "iterations_in_flight 1, graph_replay false: the reference's accumulation order, bit-identical image"}
         cpu = None
         if N == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(scene_path, res, a.depth, mode, a.cpu_seconds)
         out = {
             "metric": "Mrays/s (paths x bounces / s)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak" if (weak or N == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (weak or N == 1) else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": f"the reference's own scene file scenes/{a.scene} (verbatim copy, parsed by this build's loader); no synthetic inputs, no dataset",
             "config": {"workload": f"scenes/{a.scene} {scene.width}x{scene.height} depth {scene.trace_depth}, SampleMode {a.mode.upper()}"
                                    + (" (BASELINE configs[1])" if a.scene == "cornell.txt" and res is None and a.depth < 0 and a.mode == "bsdf" else ""),
                        "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce_last_step_rank0": [int(c) for c in counts],
@@ -289,8 +348,13 @@ def main():
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
                        "pipeline": "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync"},
             "device_ms_per_step": round(dev_ms / a.steps, 4),
+            "overlap_note": (f"{a.in_flight} iterations in flight on {a.in_flight} streams: ms_per_step is smaller than the sum of the "
+                             "per-kernel times of one iteration (roofline.note) because iterations overlap") if a.in_flight > 1 else None,
+            "reference_order": ref_order,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         out.update(extra)
         print(json.dumps(out))
     if N > 1:

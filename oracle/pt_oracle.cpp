@@ -349,6 +349,9 @@ static inline float sample1D(Rng& r) {
 // g_dbg_slot_shift is an analysis knob of the gallery test only: it offsets the compacted slot in the shading RNG key
 // (the reference's GPU build flips a few sphere-silhouette hits per iteration, which shifts every later slot).
 static int g_dbg_slot_shift = 0;
+// tile partition (not a reference feature): rank `part` keys its shading RNG with slot + part * W * H * spp so that two ranks never
+// share a random stream; 0 without a partition = the reference's key (pathtrace.cu:363,458,532)
+static int g_slot_bias = 0;
 static int g_s2d_xfirst = 1;
 static inline v2 sample2D(Rng& r) { v2 o; if (g_s2d_xfirst) { o.x = sample1D(r); o.y = sample1D(r); } else { o.y = sample1D(r); o.x = sample1D(r); } return o; }
 
@@ -1013,7 +1016,7 @@ static int shade_bsdf(const OrcScene& S, int iter, int idx, int depth, const Ise
     int valid = 0;
     const Material& m = S.materials[is.materialId];
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
-    Rng rng = make_rng(iter, idx + g_dbg_slot_shift, depth);
+    Rng rng = make_rng(iter, idx + g_dbg_slot_shift + g_slot_bias, depth);
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     if (srec.pdf == 0) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
@@ -1035,7 +1038,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
     const Material& m = S.materials[is.materialId];
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
     bool isDelta = (m.type == MAT_DIELECTRIC);
-    Rng rng = make_rng(iter, idx + g_dbg_slot_shift, depth);
+    Rng rng = make_rng(iter, idx + g_dbg_slot_shift + g_slot_bias, depth);
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     v3 viewPos = is.p, viewNor = is.n;
@@ -1071,7 +1074,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
 
 // pathtrace.cu:348-403 DirectLiPTkernel, one path (always rayValid = 0)
 static int shade_direct(const OrcScene& S, int iter, int idx, int depth, const Isect& is, PathSegment& ps, float* img) {
-    Rng rng = make_rng(iter, idx + g_dbg_slot_shift, depth);
+    Rng rng = make_rng(iter, idx + g_dbg_slot_shift + g_slot_bias, depth);
     const Material& m = S.materials[is.materialId];
     float* px = radiance_px(img, ps.pixelIndex);
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
@@ -1664,6 +1667,7 @@ long long orc_pathtrace_batch(OrcScene* S, int mode, int step, int spp, int n_pa
         }
     }
     const int key_iter = (step - 1) * spp + 1;
+    g_slot_bias = n_parts > 1 ? part * W * H * spp : 0;
     int P = (int)paths.size();
     std::vector<Isect> isects(P); std::vector<int> valid(P);
     auto t1 = clk::now();
@@ -1687,6 +1691,7 @@ long long orc_pathtrace_batch(OrcScene* S, int mode, int step, int spp, int n_pa
         ts += std::chrono::duration<double>(d2 - c).count();
         depth++;
     }
+    g_slot_bias = 0;
     if (timing) { timing[0] += tg; timing[1] += ti; timing[2] += ts; timing[3] += tc; }
     return rays;
 }

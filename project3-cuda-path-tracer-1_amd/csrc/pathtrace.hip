@@ -41,6 +41,7 @@ struct Lane {
     hipGraphExec_t graph_exec = nullptr;
     int graph_mode = -1;
     int expected_iter = 0;              // value *iter_dev will hold when the next replay starts
+    bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
 };
 
 struct RenderContext {
@@ -48,6 +49,7 @@ struct RenderContext {
     GuiDataContainer* gui = nullptr;
     std::vector<Lane> lanes;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t resolved = nullptr;      // recorded on lane 0 after k_sum_planes
     float* planes = nullptr;            // float[L][3*P]
     float* image = nullptr;             // float[3*P]: plane sum when L > 1 (== planes when L == 1)
     unsigned long long* ray_total = nullptr;
@@ -99,6 +101,7 @@ int context_free() {
     dfree(g.planes); dfree(g.ray_total);
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
+    if (g.resolved) { (void)hipEventDestroy(g.resolved); g.resolved = nullptr; }
     g.live = false; g.scene = nullptr; g.P = g.capacity = 0;
     return 0;
 }
@@ -121,6 +124,8 @@ int lane_init(Lane& l, int idx) {
     l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
     l.ws.plane_stride = 3u * (unsigned)g.P;
     l.ws.spp = g.spp;
+    // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
+    l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;
     if ((rc = alloc_paths(l.bufA, g.capacity))) return rc;
     if ((rc = alloc_paths(l.bufB, g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
@@ -178,6 +183,7 @@ int context_init(Scene* scene) {
     hipError_t e;
     if ((e = hipEventCreate(&g.ev0)) != hipSuccess) return (int)e;
     if ((e = hipEventCreate(&g.ev1)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreateWithFlags(&g.resolved, hipEventDisableTiming)) != hipSuccess) return (int)e;
     const size_t plane = 3 * (size_t)g.P;
     const size_t n_planes = (size_t)g.n_lanes * g.spp;
     if ((rc = dalloc(&g.planes, plane * n_planes))) return rc;
@@ -289,6 +295,11 @@ int render_iteration(unsigned char* pbo, int iter) {
     g.last_lane = li;
     L.last_iter = iter;
     g_prof.stream = L.stream;
+    if (L.wait_resolved) {                   // lane 0 may still be summing this lane's plane for the previous pbo
+        const hipError_t e = hipStreamWaitEvent(L.stream, g.resolved, 0);
+        if (e != hipSuccess) return (int)e;
+        L.wait_resolved = false;
+    }
     const int mode = current_mode();
     if (g.use_graph && !g_prof.on && !L.ws.stats) return replay_iteration(L, iter, mode);
     L.expected_iter = -1;
@@ -310,7 +321,12 @@ int resolve_image() {
     int rc = join_on_lane0();
     if (rc) return rc;
     if (g.n_lanes * g.spp > 1) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
-    return rc;
+    if (rc || g.n_lanes == 1) return rc;
+    // the other lanes' next iterations write the planes this sum reads: they wait for it (event edge, no host wait)
+    const hipError_t e = hipEventRecord(g.resolved, g.lanes[0].stream);
+    if (e != hipSuccess) return (int)e;
+    for (size_t i = 1; i < g.lanes.size(); ++i) g.lanes[i].wait_resolved = true;
+    return 0;
 }
 
 [[noreturn]] void die(const char* msg, int rc, const char* file, int line) {      // checkCUDAErrorFn, scene.cpp:20-38
@@ -348,10 +364,11 @@ int ptk_set_iterations_in_flight(int lanes) {
 /* Shading kernel layout: 256 (default) = the paths of each 256-path block are counting-sorted by material type before shading;
  * 0 = one path per thread in path order (honoured by pipeline 4 only: block-local compaction needs the binned kernel).
  * 512- and 1024-path bins were measured slower and are gone.  Identical results. */
-int ptk_set_shade_binning(int block) { if (block != 0 && block != 256) return PTK_E_BADARG; set_shade_bin(block); return 0; }
+static void invalidate_graphs() { for (Lane& l : g.lanes) l.graph_mode = -1; }     // captured launches bake these knobs in: recapture
+int ptk_set_shade_binning(int block) { if (block != 0 && block != 256) return PTK_E_BADARG; set_shade_bin(block); invalidate_graphs(); return 0; }
 /* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
-int ptk_set_light_fix(int on) { set_light_fix(on != 0); return 0; }
-int ptk_set_fused_block(int threads) { if (threads != 256 && threads != 512) return PTK_E_BADARG; set_fused_block(threads); return 0; }
+int ptk_set_light_fix(int on) { set_light_fix(on != 0); invalidate_graphs(); return 0; }
+int ptk_set_fused_block(int threads) { if (threads != 256 && threads != 512) return PTK_E_BADARG; set_fused_block(threads); invalidate_graphs(); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
 int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
 
@@ -430,6 +447,7 @@ int ptk_set_pipeline(int which) {
     g.pipeline = which;
     for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which != 4 && which != 5 && which != 6); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); }
     set_uniform_analytic(which == 2);
+    invalidate_graphs();
     return 0;
 }
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the

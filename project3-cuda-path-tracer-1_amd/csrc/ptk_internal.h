@@ -56,6 +56,8 @@ struct Workspace {               // per-render-context scratch, device memory
     int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
     unsigned plane_stride = 0;   // floats per radiance plane (3*P)
     int spp = 1;                 // samples (iterations) per launch
+    int slot_bias = 0;           // added to the compacted slot in the shading RNG key: part * W * H * spp under the tile partition, so
+                                 // that two ranks never share a random stream (0 on one GPU = the reference's key)
     // fused bounce kernel (pipeline 3): ticket counter, launch tag and the two scan status tables [blocks]
     unsigned* ticket = nullptr; unsigned* epoch = nullptr;
     unsigned long long* st_hit = nullptr; unsigned long long* st_live = nullptr;

@@ -664,7 +664,7 @@ template <int MODE, bool VIRTUAL>
 __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n,
                                                       PtkHits hits, PtkPaths paths, const int* __restrict__ valid_a,
                                                       const int* __restrict__ agg_a, int* __restrict__ valid_b,
-                                                      int* __restrict__ agg_b, float* __restrict__ img_base, unsigned plane_stride, int spp) {
+                                                      int* __restrict__ agg_b, float* __restrict__ img_base, unsigned plane_stride, int spp, int slot_bias) {
     const int n = d_n ? *d_n : n_arg;
     const int iter = ((iter_ptr ? *iter_ptr : iter_arg) - 1) * spp + 1;     // RNG key: first iteration of this launch's batch
     const Film img = {img_base, plane_stride};
@@ -681,6 +681,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
         const int local = block_excl_prefix(flag, total);
         slot = prior_blocks(agg_a, b) + local;
     }
+    slot += slot_bias;           // tile partition: rank-unique keys (0 on a single GPU)
     int alive = 0;
     if (flag) {
         const float4 h0 = ld4(hits.t_n, i), h1 = ld4(hits.p_mat, i);
@@ -717,7 +718,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
                                                       const int* __restrict__ d_n, PtkHits hits, PtkPaths paths,
                                                       const int* __restrict__ valid_a, const int* __restrict__ agg_a,
                                                       int* __restrict__ valid_b, int* __restrict__ agg_b,
-                                                      float* __restrict__ img_base, unsigned plane_stride, int spp,
+                                                      float* __restrict__ img_base, unsigned plane_stride, int spp, int slot_bias,
                                                       const int* __restrict__ srcidx, PtkPaths seg_out) {
     // srcidx  : physical slot of every dense path (segmented input stream), nullptr = the stream is dense
     // seg_out : non-null streams = block-local compaction: survivors go to seg_out[b * NT + rank within the block] and agg_b[b] is
@@ -770,7 +771,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
         else if (key > k) rank += total;
     }
     s_perm[rank] = tid;
-    s_slot[tid] = prior + hits_before;
+    s_slot[tid] = prior + hits_before + slot_bias;      // slot_bias: rank-unique RNG keys under the tile partition (0 on one GPU)
     __syncthreads();
     // --- sorted order: thread `tid` shades item src
     int alive = 0, src = -1;
@@ -987,7 +988,7 @@ struct FusedArgs {
     int iter_arg; const int* iter_ptr; int depth;
     int n_arg; const int* d_n;
     PtkPaths cur, nxt;
-    float* img; unsigned plane_stride; int spp;
+    float* img; unsigned plane_stride; int spp; int slot_bias;
     int* count_out;                          // live paths entering the next bounce
     unsigned long long* ray_total;
     unsigned long long* stats;
@@ -1032,7 +1033,7 @@ __global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
         const float4 c4 = ld4(A.cur.col_pdf, i);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
         const MatTable mt = {nullptr, 0};
-        alive = shade_path<MODE>(S, gs, mt, iter, prior + local, A.depth, h, p, img);
+        alive = shade_path<MODE>(S, gs, mt, iter, prior + local + A.slot_bias, A.depth, h, p, img);
     }
     int total2;
     const int local2 = block_excl_prefix_n<NT>(alive, total2);
@@ -1149,14 +1150,14 @@ int g_shade_bin = 256;                 // 0: plain k_shade (pipeline 4 only); 25
 
 template <int NT>
 int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                        const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st,
+                        const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
                         const int* srcidx, PtkPaths seg_out) {
     const int g = (n + NT - 1) / NT;
     if (g == 0) return 0;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, srcidx, seg_out); break;
-    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, srcidx, seg_out); break;
-    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, srcidx, seg_out); break;
+    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -1164,17 +1165,17 @@ int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_
 
 template <bool V>
 int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                 const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, hipStream_t st,
+                 const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
                  const int* srcidx = nullptr, PtkPaths seg_out = PtkPaths{nullptr, nullptr, nullptr}) {
-    if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, srcidx, seg_out);
+    if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, srcidx, seg_out);
     if (srcidx) return PTK_E_BADARG;       // only the segmented pipeline addresses paths indirectly
-    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, st, nullptr, seg_out);
+    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, nullptr, seg_out);
     const int g = grid_for(n);
     if (g == 0) return 0;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
-    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp); break;
+    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias); break;
+    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias); break;
+    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -1290,7 +1291,7 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
         if ((rc = launch_rc())) return rc;
     }
     mark(2, true);
-    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, st,
+    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, ws.slot_bias, st,
                             G.src, seg ? nxt : PtkPaths{nullptr, nullptr, nullptr});
     mark(2, false);
     if (rc) return rc;
@@ -1320,7 +1321,7 @@ int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int c
     A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth = depth;
     A.n_arg = capacity; A.d_n = ws.counts + depth;
     A.cur = cur; A.nxt = nxt;
-    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp;
+    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
     A.count_out = ws.counts + depth + 1;
     A.ray_total = ws.ray_total; A.stats = ws.stats;
     A.ticket = ws.ticket; A.epoch = ws.epoch; A.st_hit = ws.st_hit; A.st_live = ws.st_live;
@@ -1410,7 +1411,7 @@ int ptk_shade(const PtkScene* s, int mode, int iter, int depth, int n, const int
     if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid || !img) return PTK_E_BADARG;
     if (n == 0) return 0;
-    return launch_shade<false>(mode, dev_view(*s->scene), iter, nullptr, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, 0u, 1, (hipStream_t)stream);
+    return launch_shade<false>(mode, dev_view(*s->scene), iter, nullptr, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, 0u, 1, 0, (hipStream_t)stream);
 }
 
 int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char* pbo, void* stream) {

@@ -344,6 +344,29 @@ def test_pathtrace_fills_the_pbo(ptk, orc, torch_cuda, lanes):
     r.close()
 
 
+def test_pbo_without_host_sync(ptk, orc, torch_cuda):
+    """with iterations in flight, ptk_pathtrace(pbo) sums the planes on lane 0 asynchronously while the next call
+    may already write another lane's plane.  The lanes now wait for that sum (event edge).  Six calls with a pbo and NO host
+    synchronisation in between; after the last one the pbo is the display transform of the exact six-iteration sum."""
+    torch = torch_cuda
+    name, res, depth, lanes = "cornell.txt", (256, 256), 6, 3
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes, graph=True)
+    pbo = torch.zeros((o.P, 4), dtype=torch.uint8, device="cuda")
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    for it in range(1, 7):
+        r.iterate(it, pbo=pbo)
+    for it in range(1, 7):
+        o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+    r.sync()
+    ref_img = (planes[0] + planes[1]) + planes[2]
+    assert np.array_equal(r.image(), ref_img)
+    ref = np.zeros((o.P, 4), np.uint8); orc.L.orc_tonemap(ref_img.ctypes.data, o.P, 6, ref.ctypes.data)
+    assert np.abs(pbo.cpu().numpy().astype(int) - ref.astype(int)).max() <= 1
+    r.close()
+
+
 def test_tile_partition(ptk, orc, torch_cuda):
     """Multi-GPU sharding: each part renders its interleaved row tiles; every part equals the oracle run with
     the same partition, parts are disjoint, and the summed image is a valid full-frame render (same live pixels)."""
@@ -452,6 +475,7 @@ FULL = [  # BASELINE.json configs at full size (oracle: a few seconds per iterat
     ("cornell.txt", None, -1, "BSDF", 2),             # configs[1]: 800x800 depth 8
     ("bunny_cornell.txt", None, -1, "BSDF", 1),       # configs[2] timed scene: 800x800 depth 8, 10k triangles
     ("mis_test.txt", (1024, 1024), 16, "MIS", 2),     # configs[3]
+    ("metallic_analytic.txt", (1024, 1024), 16, "MIS", 1),   # configs[3]'s "full BSDF set": MetallicWorkflow + Dielectric + Microfacet + Lambertian
 ]
 
 
@@ -472,10 +496,54 @@ def test_full_size_configs(ptk, orc, torch_cuda, name, res, depth, mode, iters):
     assert not bad.any(), f"{int(bad.sum())} of {len(ref)} pixels differ"
 
 
+def test_benchmarked_configuration_full_size(ptk, orc, torch_cuda):
+    """What bench.py times by default: cornell.txt 800x800 depth 8, BSDF, THREE iterations in flight + hipGraph
+    replay, six iterations (every lane replays its graph): per-iteration live counts == oracle, image == the oracle's three
+    planes summed in lane order ((p0 + p1) + p2), bit for bit."""
+    name, lanes = "cornell.txt", 3
+    s = ptk.Scene(os.path.join(SC, name)); o = orc.Scene(os.path.join(SC, name))
+    assert (s.width, s.height, s.trace_depth) == (800, 800, 8)
+    r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes, graph=True)
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    orc.set_threads(os.cpu_count() or 1)
+    try:
+        for it in range(1, 7):
+            r.iterate(it)
+            _, live = o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, live), (it, counts, live)
+    finally:
+        orc.set_threads(1)
+    img = r.image(); r.close()
+    assert np.array_equal(img, (planes[0] + planes[1]) + planes[2])
+
+
+def test_configs4_tile_part_full_size(ptk, orc, torch_cuda):
+    """BASELINE configs[4]: the bunny scene at 2048x2048 depth 16, split over 8 ranks by interleaved 8-row tiles.  One rank's
+    share (part 3 of 8: 524 288 paths, its own compaction order and rank-unique RNG keys) == the oracle's run of the same
+    part, bit for bit; the other seven parts only through their supports (test_full_size_properties_2048)."""
+    res, depth, part = (2048, 2048), 16, (8, 3, 8)
+    s = ptk.Scene(os.path.join(SC, "bunny_cornell.txt"), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, "bunny_cornell.txt"), res=res, depth=depth)
+    r = ptk.Renderer(s, ptk.MODE_BSDF, partition=part)
+    r.iterate(1)
+    img = r.image(); counts, _ = r.live_counts(); r.close()
+    planes = np.zeros((1, o.P, 3), np.float32)
+    orc.set_threads(os.cpu_count() or 1)
+    try:
+        _, live = o.pathtrace_batch(ptk.MODE_BSDF, 1, 1, planes, partition=part)
+    finally:
+        orc.set_threads(1)
+    assert counts[0] == 2048 * 2048 // 8 and np.array_equal(counts, live), (counts, live)
+    assert np.array_equal(img, planes[0]), int((img != planes[0]).any(axis=1).sum())
+
+
 def test_full_size_properties_2048(ptk, torch_cuda):
     """configs[4] size (2048x2048 depth 16, bunny scene) through size-independent properties: determinism (two renders
-    are identical), additivity over iterations, every radiance finite and >= 0, live counts non-increasing, tiles sum
-    to disjoint supports."""
+    are identical), additivity over iterations, every radiance finite and >= 0, live counts non-increasing; and the 8-way
+    tile partition: every part touches only its own rows, the parts' path counts add up to the frame, and the parts
+    together light the same pixels as the whole-frame render up to noise (their sum is NOT the whole-frame image: the
+    shading RNG is keyed by each rank's own compacted slots)."""
     s = ptk.Scene(os.path.join(SC, "bunny_cornell.txt"), res=(2048, 2048), depth=16)
     r = ptk.Renderer(s, 0)
     r.iterate(1); a = r.image(); c1, _ = r.live_counts()
@@ -489,6 +557,18 @@ def test_full_size_properties_2048(ptk, torch_cuda):
     assert c1[0] == 2048 * 2048 and (np.diff(c1) <= 0).all()
     # additivity: image after iterations {1,2} == image(1) + image(2) (same float additions per pixel, in order)
     assert np.array_equal(ab, a + b)
+    rows = np.arange(2048)
+    total = np.zeros_like(a); n_paths = 0
+    for part in range(8):
+        r = ptk.Renderer(s, 0, partition=(8, part, 8))
+        r.iterate(1); p = r.image(); c, _ = r.live_counts(); r.close()
+        own = ((rows // 8) % 8) == part
+        assert not p.reshape(2048, 2048, 3)[~own].any(), part          # nothing outside the part's tiles
+        assert np.isfinite(p).all() and (p >= 0).all()
+        total += p; n_paths += int(c[0])
+    assert n_paths == 2048 * 2048
+    # same estimator, different random streams: global means agree statistically (1 spp: 2 % tolerance; measured < 0.5 %)
+    assert abs(total.mean() - a.mean()) < 0.02 * a.mean(), (total.mean(), a.mean())
 
 
 def _many_primitives_scene(path, n_geoms, seed):
@@ -525,7 +605,7 @@ def _many_primitives_scene(path, n_geoms, seed):
         f.write("\n".join(L) + "\n")
 
 
-@pytest.mark.parametrize("n_geoms,mode", [(70, "MIS"), (33, "BSDF"), (140, "DIRECT")])
+@pytest.mark.parametrize("n_geoms,mode", [(70, "MIS"), (33, "BSDF"), (140, "DIRECT"), (512, "BSDF"), (513, "MIS")])
 def test_many_primitives(ptk, orc, torch_cuda, tmp_path, n_geoms, mode):
     """More analytic primitives than one 32-wide candidate chunk, rotated and overlapping: images and live counts == oracle,
     for the staged candidate loops (default) and for the wave-uniform loops (pipeline 2)."""
