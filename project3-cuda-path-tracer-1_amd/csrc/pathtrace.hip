@@ -41,6 +41,7 @@ struct Lane {
     hipGraphExec_t graph_exec = nullptr;
     int graph_mode = -1;
     int expected_iter = 0;              // value *iter_dev will hold when the next replay starts
+    int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
     bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
 };
 
@@ -87,7 +88,7 @@ int context_free() {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
-        dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first);
+        dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
         dfree(l.ws.ticket); dfree(l.ws.epoch); dfree(l.ws.st_hit); dfree(l.ws.st_live);
         dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
@@ -143,6 +144,10 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.srcidx, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.ws.seg_pref, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.seg_first, blocks + 16))) return rc;
+    const size_t n_done = 32 * ((size_t)blocks / 32 + 3);          // top counter + one per 32 blocks, each on its own 128-B line (segments_tail)
+    if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
+    if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
+    l.ws.seg_done = g.pipeline == 7 ? nullptr : l.seg_done_mem;
     if ((rc = dalloc(&l.ws.ticket, 1))) return rc;
     if ((rc = dalloc(&l.ws.epoch, 1))) return rc;
     if ((rc = dalloc(&l.ws.st_hit, blocks))) return rc;
@@ -158,7 +163,7 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
-    l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline != 4 && g.pipeline != 5 && g.pipeline != 6);
+    l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline != 4 && g.pipeline != 5 && g.pipeline != 6 && g.pipeline != 7);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.fused = (g.pipeline == 3);
     l.ws.segmented = (g.pipeline != 4);
@@ -443,9 +448,9 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     return x + y * W;
 }
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 6) return PTK_E_BADARG;
+    if (which < 0 || which > 7) return PTK_E_BADARG;
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which != 4 && which != 5 && which != 6); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which != 4 && which != 5 && which != 6 && which != 7); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.seg_done = which == 7 ? nullptr : l.seg_done_mem; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     return 0;

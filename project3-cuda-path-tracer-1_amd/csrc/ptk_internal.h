@@ -64,6 +64,8 @@ struct Workspace {               // per-render-context scratch, device memory
     bool fused = false;          // pipeline 3
     // segmented path streams (default): physical slot of every dense path, window prefix and first-window tables
     int* srcidx = nullptr; int* seg_pref = nullptr; int* seg_first = nullptr;
+    int* seg_done = nullptr;     // blocks of the running shading kernel that have published their survivor count (segments_tail); null:
+                                 // a separate k_segments launch does the bookkeeping (pipeline 7, A/B)
     bool segmented = true;       // false: k_scatter moves the survivors (pipeline 4)
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)

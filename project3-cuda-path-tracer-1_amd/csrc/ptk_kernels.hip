@@ -708,6 +708,97 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
     }
 }
 
+// Segmented streams, bookkeeping between two bounces: exclusive prefix of the per-window survivor counts (seg_pref), the
+// window that holds the first path of every dense 256-range (seg_first), the live count of the next bounce, and (last bounce
+// of an iteration) the step of the device-resident iteration number.  A window holds at most 256 paths, so it contains at
+// most one multiple of 256 of the dense order: seg_first is written by scatter, no search.
+// Run by ONE block of NT threads: by k_segments (pipeline 4 / A-B), or — default — by the LAST block of the shading kernel
+// to finish (segments_tail below), which saves a one-block launch (7 us + the launch gap) per bounce.  AGENT: agg[] was
+// written by other workgroups of the SAME launch: read it with agent-scope (sc1) loads, never from this CU's L1.
+template <int NT, bool AGENT>
+__device__ __forceinline__ void segments_block(int n_prev, const int* __restrict__ agg, int* __restrict__ pref, int* __restrict__ first,
+                                               int* __restrict__ count_out, int* iter_advance, int iter_stride) {
+    constexpr int NW = NT / 64;
+    __shared__ int s_w[NW];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nw = n_prev > 0 ? (n_prev + PTK_BLOCK - 1) / PTK_BLOCK : 0;          // windows the shading kernel wrote
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nw; base += 4 * NT) {                        // four consecutive windows per thread
+        const int idx = base + 4 * tid;
+        int4 c = make_int4(0, 0, 0, 0);
+        if (AGENT) {
+            if (idx < nw) c.x = __hip_atomic_load(agg + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx + 1 < nw) c.y = __hip_atomic_load(agg + idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx + 2 < nw) c.z = __hip_atomic_load(agg + idx + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx + 3 < nw) c.w = __hip_atomic_load(agg + idx + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (idx + 3 < nw) c = *reinterpret_cast<const int4*>(agg + idx);   // agg is 16-byte aligned (hipMalloc) and idx % 4 == 0
+        else { if (idx < nw) c.x = agg[idx]; if (idx + 1 < nw) c.y = agg[idx + 1]; if (idx + 2 < nw) c.z = agg[idx + 2]; }
+        const int v = c.x + c.y + c.z + c.w;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_w[wid] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int cw = s_w[w]; woff += (w < wid) ? cw : 0; tot += cw; }
+        const int carry = s_carry;
+        int excl = carry + woff + incl - v;
+        const int cnt[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (idx + k < nw) {
+                pref[idx + k] = excl;
+                const int B = (excl + PTK_BLOCK - 1) / PTK_BLOCK;
+                if (cnt[k] > 0 && B * PTK_BLOCK < excl + cnt[k]) first[B] = idx + k;
+            }
+            excl += cnt[k];
+        }
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    const int total = s_carry;
+    if (tid < 8) pref[nw + tid] = total;                   // gather_source reads up to 4 entries past its window
+    if (tid == 0) {
+        if (count_out) *count_out = total;
+        if (iter_advance) *iter_advance += iter_stride;    // last work of an iteration: step the device-resident iteration number
+    }
+}
+
+// Tail of the shading kernel (segmented streams): every block publishes its survivor count with an agent-scope store,
+// waits for it (s_waitcnt vmcnt(0)) and counts itself done; the block that completes the count is the last one, sees every
+// count (MI355X_MICROARCH.md, inter-workgroup visibility: one lane per workgroup signals after its stores' vmcnt(0), the
+// workgroup whose add came last loads after the add has returned, its other waves after a workgroup barrier; payload stored
+// and loaded sc1) and runs segments_block.
+// The count is a two-level tree — one counter per PTK_SEG_GROUP blocks, each on its own 128-B line, and a top counter the
+// last block of every group adds to — because agent-scope atomics on ONE word serialise at ~11 ns each: 2 500 blocks on a
+// single counter cost +17 us per launch (measured), 32 per counter in parallel ~0.4 us.  The last block also clears the
+// counters for the next launch.
+#define PTK_SEG_GROUP 32
+struct SegTail { int* done; int* pref; int* first; int* count_out; int* iter_advance; int iter_stride; };
+template <int NT>
+__device__ __forceinline__ void segments_tail(const SegTail& T, int n, int b, int total, int* __restrict__ agg_b) {
+    __shared__ int s_last;
+    const int nb = (n + NT - 1) / NT, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(agg_b + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int grp = b / PTK_SEG_GROUP;
+        const int gsize = min(PTK_SEG_GROUP, nb - grp * PTK_SEG_GROUP);
+        int last = 0;
+        if (__hip_atomic_fetch_add(T.done + 32 * (grp + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1)
+            last = __hip_atomic_fetch_add(T.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int k = threadIdx.x; k <= ng; k += NT) __hip_atomic_store(T.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    segments_block<NT, true>(n, agg_b, T.pref, T.first, T.count_out, T.iter_advance, T.iter_stride);
+}
+
 // Material-binned shading (pipeline default).  The BSDF switch of Material::scatterSample is the divergent part of shading
 // (Lambertian ~350, Microfacet ~600, Dielectric ~250, Light ~50 VALU; a wave with a mix executes them all).  A block of NT
 // consecutive paths is counting-sorted by material type in LDS and thread j shades the j-th path of that order, so most waves
@@ -719,7 +810,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
                                                       const int* __restrict__ valid_a, const int* __restrict__ agg_a,
                                                       int* __restrict__ valid_b, int* __restrict__ agg_b,
                                                       float* __restrict__ img_base, unsigned plane_stride, int spp, int slot_bias,
-                                                      const int* __restrict__ srcidx, PtkPaths seg_out) {
+                                                      const int* __restrict__ srcidx, PtkPaths seg_out, SegTail seg_tail) {
     // srcidx  : physical slot of every dense path (segmented input stream), nullptr = the stream is dense
     // seg_out : non-null streams = block-local compaction: survivors go to seg_out[b * NT + rank within the block] and agg_b[b] is
     //           their number (valid_b unused); null = update the paths in place and flag the survivors in valid_b (k_scatter follows)
@@ -732,7 +823,11 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
     const int iter = ((iter_ptr ? *iter_ptr : iter_arg) - 1) * spp + 1;
     const Film img = {img_base, plane_stride};
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (b * NT >= n) return;
+    if (b * NT >= n) {
+        // no live path at all: nobody runs the tail, block 0 does the (empty) bookkeeping of the bounce
+        if (n <= 0 && b == 0 && seg_tail.done) segments_block<NT, false>(0, agg_b, seg_tail.pref, seg_tail.first, seg_tail.count_out, seg_tail.iter_advance, seg_tail.iter_stride);
+        return;
+    }
     GeomStage gs; gs.xf = nullptr; gs.on = false;
     if (MODE != PTK_MODE_BSDF) gs = stage_geoms(S);
     __shared__ DevMaterial s_mats[PTK_LDS_MATS];
@@ -820,7 +915,8 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
             st4(seg_out.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
             st4(seg_out.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
         }
-        if (tid == 0) agg_b[b] = total;
+        if (seg_tail.done) segments_tail<NT>(seg_tail, n, b, total, agg_b);       // the last block to get here finishes the bounce
+        else if (tid == 0) agg_b[b] = total;
         return;
     }
     if (tid < SUB && (b * SUB + tid) * PTK_BLOCK < n) {
@@ -1053,56 +1149,11 @@ __global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
     }
 }
 
-// Segmented streams, bookkeeping between two bounces (one block): exclusive prefix of the per-window survivor counts, the
-// window that holds the first path of every dense 256-range, and the live count of the next bounce.  A window holds at
-// most 256 paths, so it contains at most one multiple of 256 of the dense order: seg_first is written by scatter, no search.
+// stand-alone form of segments_block (one block; used when the shading kernel does not run the tail itself)
 #define PTK_SEG_BLOCK 1024
 __global__ void __launch_bounds__(PTK_SEG_BLOCK) k_segments(int n_arg, const int* __restrict__ d_n, const int* __restrict__ agg, int* __restrict__ pref,
                                                             int* __restrict__ first, int* __restrict__ count_out, int* iter_advance, int iter_stride) {
-    constexpr int NW = PTK_SEG_BLOCK / 64;
-    __shared__ int s_w[NW];
-    __shared__ int s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int n_prev = d_n ? *d_n : n_arg;
-    const int nw = n_prev > 0 ? (n_prev + PTK_BLOCK - 1) / PTK_BLOCK : 0;          // windows the shading kernel wrote
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nw; base += 4 * PTK_SEG_BLOCK) {             // four consecutive windows per thread: one pass up to 4096 windows
-        const int idx = base + 4 * tid;
-        int4 c = make_int4(0, 0, 0, 0);
-        if (idx + 3 < nw) c = *reinterpret_cast<const int4*>(agg + idx);  // agg is 16-byte aligned (hipMalloc) and idx % 4 == 0
-        else { if (idx < nw) c.x = agg[idx]; if (idx + 1 < nw) c.y = agg[idx + 1]; if (idx + 2 < nw) c.z = agg[idx + 2]; }
-        const int v = c.x + c.y + c.z + c.w;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) s_w[wid] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { const int cw = s_w[w]; woff += (w < wid) ? cw : 0; tot += cw; }
-        const int carry = s_carry;
-        int excl = carry + woff + incl - v;
-        const int cnt[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (idx + k < nw) {
-                pref[idx + k] = excl;
-                const int B = (excl + PTK_BLOCK - 1) / PTK_BLOCK;
-                if (cnt[k] > 0 && B * PTK_BLOCK < excl + cnt[k]) first[B] = idx + k;
-            }
-            excl += cnt[k];
-        }
-        __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
-        __syncthreads();
-    }
-    const int total = s_carry;
-    if (tid < 8) pref[nw + tid] = total;                   // gather_source reads up to 4 entries past its window
-    if (tid == 0) {
-        if (count_out) *count_out = total;
-        if (iter_advance) *iter_advance += iter_stride;    // last kernel of an iteration: step the device-resident iteration number
-    }
+    segments_block<PTK_SEG_BLOCK, false>(d_n ? *d_n : n_arg, agg, pref, first, count_out, iter_advance, iter_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1151,13 +1202,13 @@ int g_shade_bin = 256;                 // 0: plain k_shade (pipeline 4 only); 25
 template <int NT>
 int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
                         const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
-                        const int* srcidx, PtkPaths seg_out) {
+                        const int* srcidx, PtkPaths seg_out, SegTail seg_tail) {
     const int g = (n + NT - 1) / NT;
     if (g == 0) return 0;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out); break;
-    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out); break;
-    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out); break;
+    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -1166,10 +1217,11 @@ int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_
 template <bool V>
 int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
                  const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
-                 const int* srcidx = nullptr, PtkPaths seg_out = PtkPaths{nullptr, nullptr, nullptr}) {
-    if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, srcidx, seg_out);
+                 const int* srcidx = nullptr, PtkPaths seg_out = PtkPaths{nullptr, nullptr, nullptr},
+                 SegTail seg_tail = SegTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
+    if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, srcidx, seg_out, seg_tail);
     if (srcidx) return PTK_E_BADARG;       // only the segmented pipeline addresses paths indirectly
-    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, nullptr, seg_out);
+    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, nullptr, seg_out, SegTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     const int g = grid_for(n);
     if (g == 0) return 0;
     switch (mode) {
@@ -1291,10 +1343,12 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
         if ((rc = launch_rc())) return rc;
     }
     mark(2, true);
+    const bool fold = seg && ws.seg_done != nullptr;         // the shading kernel's last block does the window bookkeeping itself
+    const SegTail tail = {fold ? ws.seg_done : nullptr, ws.seg_pref, ws.seg_first, ws.counts + depth + 1, last_bounce ? ws.iter_dev : nullptr, ws.iter_stride};
     rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, ws.slot_bias, st,
-                            G.src, seg ? nxt : PtkPaths{nullptr, nullptr, nullptr});
+                            G.src, seg ? nxt : PtkPaths{nullptr, nullptr, nullptr}, tail);
     mark(2, false);
-    if (rc) return rc;
+    if (rc || fold) return rc;
     if (seg) {                              // survivors are already in nxt, window by window: only the bookkeeping is left
         mark(3, true);
         k_segments<<<1, PTK_SEG_BLOCK, 0, st>>>(capacity, d_n, ws.agg_b, ws.seg_pref, ws.seg_first, ws.counts + depth + 1,
