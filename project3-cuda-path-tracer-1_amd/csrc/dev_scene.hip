@@ -3,7 +3,7 @@
 //
 // HBM layout (all read-only during rendering, replicated per GPU; a few MB at most):
 //   DevGeom[G]      144 B each : analytic primitives, matrices as 3x4 rows  -> read through scalar loads
-//   DevMaterial[M]   48 B each : constant BSDF parameters (roughness/metallic pre-clamped)
+//   DevMaterial[M]   80 B each : constant BSDF parameters (roughness/metallic pre-clamped)
 //   DevNode[6][B]    32 B each : AABB + the two links of one direction-ordered threaded BVH, leaf/triangle folded into the
 //                                link words (two 16-B loads per node visit; the reference's GpuBVHNode is 40 B)
 //   DevTriE[T]       48 B each : v0 + the two edges (what a triangle test touches; the reference copies 124 B)
@@ -126,6 +126,7 @@ int DevScene::initiate(Scene& scene) {
         m[i].rough = clampG(s.roughnessSampler, static_cast<float>(1e-3), 1.f);     // material.h:274, 486
         m[i].metal = clampG(s.metallicSampler, 0.f, 1.f);                           // material.h:325, 487
         m[i].ior = s.ior;
+        for (int k = 0; k < 3; ++k) m[i].albedo_pi[k] = m[i].albedo_s[k] / PTK_PI;      // correctly rounded fp32 division, as on the device
         const int T = (int)scene.textures.size();                                   // scene.cpp:597-618: bind maps that exist
         m[i].albedo_tex = (s.albedoMapID >= 0 && s.albedoMapID < T) ? s.albedoMapID : -1;
         m[i].rough_tex = (s.roughnessMapID >= 0 && s.roughnessMapID < T) ? s.roughnessMapID : -1;

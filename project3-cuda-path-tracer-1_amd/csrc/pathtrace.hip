@@ -41,6 +41,10 @@ struct Lane {
     hipGraphExec_t graph_exec = nullptr;
     int graph_mode = -1;
     int expected_iter = 0;              // value *iter_dev will hold when the next replay starts
+    int* h_counts = nullptr;            // pinned host copy of ws.counts of an earlier iteration (asynchronous read-back, never waited for)
+    hipEvent_t counts_ev = nullptr;
+    bool counts_pending = false;
+    int graph_full = -1;                // full-width bounces the captured graph contains
     int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
     bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
 };
@@ -59,6 +63,7 @@ struct RenderContext {
     int pipeline = 0, n_lanes = 1, spp = 1, n_pix = 0;
     bool use_graph = false;
     int last_lane = 0;
+    int full_bounces = 0;               // bounces enqueued at full width; the rest of an iteration runs in k_tail (sparse_tail())
     bool live = false;
 } g;
 
@@ -94,6 +99,8 @@ int context_free() {
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
         if (l.graph) (void)hipGraphDestroy(l.graph);
         if (l.done) (void)hipEventDestroy(l.done);
+        if (l.counts_ev) (void)hipEventDestroy(l.counts_ev);
+        if (l.h_counts) (void)hipHostFree(l.h_counts);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     g.lanes.clear();
@@ -111,6 +118,14 @@ int context_free() {
 // wide walk; otherwise the wide walk (shortest dependent chain) when one iteration runs at a time, and the threaded walk
 // (fewest instructions) when several iterations in flight keep the machine full.  Measured on the bunny scene, Grays/s:
 // 1 in flight 2.42 threaded / 2.86 wide; 3 in flight 4.90 / 4.34.
+// Window bookkeeping of the segmented streams: by the shading kernel's last block (pipeline 8, default with several iterations in
+// flight: one launch less per bounce, +2 % on the headline) or by a separate one-block k_segments launch (pipeline 7, default with
+// one iteration at a time, where the serial tail of that last block costs more than the launch: 0.352 vs 0.363 ms per iteration).
+static bool fold_segments(int pipeline, int n_lanes) {
+    if (pipeline == 7) return false;
+    if (pipeline == 8) return true;
+    return n_lanes > 1;
+}
 static int pick_walk(int pipeline, int n_lanes) {
     if (pipeline == 5) return PTK_WALK_THREADED;
     if (pipeline == 6) return PTK_WALK_WIDE;
@@ -122,6 +137,8 @@ int lane_init(Lane& l, int idx) {
     hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * ((size_t)g.traceDepth + 2), hipHostMallocDefault)) != hipSuccess) return (int)e;
     l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
     l.ws.plane_stride = 3u * (unsigned)g.P;
     l.ws.spp = g.spp;
@@ -147,7 +164,7 @@ int lane_init(Lane& l, int idx) {
     const size_t n_done = 32 * ((size_t)blocks / 32 + 3);          // top counter + one per 32 blocks, each on its own 128-B line (segments_tail)
     if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
     if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
-    l.ws.seg_done = g.pipeline == 7 ? nullptr : l.seg_done_mem;
+    l.ws.seg_done = fold_segments(g.pipeline, g.n_lanes) ? l.seg_done_mem : nullptr;
     if ((rc = dalloc(&l.ws.ticket, 1))) return rc;
     if ((rc = dalloc(&l.ws.epoch, 1))) return rc;
     if ((rc = dalloc(&l.ws.st_hit, blocks))) return rc;
@@ -163,7 +180,7 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
-    l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline != 4 && g.pipeline != 5 && g.pipeline != 6 && g.pipeline != 7);
+    l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline < 4);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.fused = (g.pipeline == 3);
     l.ws.segmented = (g.pipeline != 4);
@@ -180,6 +197,7 @@ int context_init(Scene* scene) {
     g.scene = scene;
     g.P = cam.resolution.x * cam.resolution.y;
     g.traceDepth = scene->state.traceDepth;
+    g.full_bounces = g.traceDepth;                  // until live counts of earlier iterations say otherwise (note_counts)
     if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
     g.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
     g.capacity = g.n_pix * g.spp;
@@ -222,6 +240,10 @@ void prof_mark(int cls, bool begin) {
     if (begin) g_prof.cls.push_back(cls);
 }
 
+// k_tail finishes the iterations of the default (segmented, staged) pipelines; pipeline 9 = every bounce at full width (A/B)
+bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 3 && g.pipeline != 4 && g.pipeline != 1 && g.pipeline != 2 && !g_prof.on &&
+                            !(g.lanes.size() && g.lanes[0].ws.stats); }
+
 int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     const Camera& cam = g.scene->state.camera;
     const SceneView S = dev_view(*g.scene);
@@ -233,8 +255,9 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     prof_mark(0, false);
     if (rc) return rc;
     PtkPaths cur = L.bufA, nxt = L.bufB;
-    for (int depth = 0; depth < g.traceDepth; ++depth) {
-        const bool last = depth == g.traceDepth - 1;
+    const int full = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
+    for (int depth = 0; depth < full; ++depth) {
+        const bool last = depth == g.traceDepth - 1;      // false for every full-width bounce when k_tail follows: it steps the iteration number
         if (ws.fused) {
             prof_mark(1, true);      // the fused kernel is reported in the intersect class
             rc = launch_bounce_fused(S, mode, iter, depth, g.capacity, cur, nxt, L.plane, ws, L.stream, last);
@@ -244,6 +267,32 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
         if (rc) return rc;
         PtkPaths t = cur; cur = nxt; nxt = t;
     }
+    if (full < g.traceDepth) {                   // every remaining bounce in one single-workgroup launch (k_tail)
+        prof_mark(1, true);
+        rc = launch_tail(S, mode, iter, full, g.traceDepth, cur, nxt, L.plane, ws, L.stream);
+        prof_mark(1, false);
+    }
+    return rc;
+}
+
+// Sparse tail (k_tail, ptk_kernels.hip).  How many bounces are worth a full-width launch is learnt from the live counts of
+// EARLIER iterations: after every iteration counts[] is copied to pinned host memory asynchronously and looked at, without
+// waiting, before a later enqueue on the same lane.  Results never depend on it — k_tail is correct for any live count.
+constexpr int kTailPaths = 1024;                 // a bounce with at most this many live paths goes to the tail (one chunk of k_tail)
+void note_counts(Lane& L) {
+    if (!L.counts_pending || hipEventQuery(L.counts_ev) != hipSuccess) return;
+    L.counts_pending = false;
+    int d_new = g.traceDepth;
+    for (int d = 1; d < g.traceDepth; ++d) if (L.h_counts[d] <= kTailPaths) { d_new = d; break; }
+    // hysteresis: widen at once, narrow only when the count is clearly below the threshold (no graph re-capture ping-pong)
+    if (d_new > g.full_bounces || (d_new < g.full_bounces && L.h_counts[d_new] <= kTailPaths / 2)) g.full_bounces = d_new;
+}
+int request_counts(Lane& L) {
+    if (!sparse_tail() || L.counts_pending) return 0;
+    hipError_t e = hipMemcpyAsync(L.h_counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipEventRecord(L.counts_ev, L.stream)) != hipSuccess) return (int)e;
+    L.counts_pending = true;
     return 0;
 }
 
@@ -268,7 +317,7 @@ int build_graph(Lane& L, int iter, int mode) {
 
 int replay_iteration(Lane& L, int iter, int mode) {
     hipError_t e;
-    if (!L.graph_exec || L.graph_mode != mode) {
+    if (!L.graph_exec || L.graph_mode != mode || L.graph_full != g.full_bounces) {
         const int rc = build_graph(L, iter, mode);
         if (rc == -1000) {
             // capture / instantiate refused by the runtime: same kernels, launched one by one (identical results)
@@ -279,7 +328,7 @@ int replay_iteration(Lane& L, int iter, int mode) {
             return enqueue_iteration(L, iter, mode, false);
         }
         if (rc) return rc;
-        L.graph_mode = mode;
+        L.graph_mode = mode; L.graph_full = g.full_bounces;
         L.expected_iter = -1;
     }
     if (L.expected_iter != iter) {           // first replay, or the caller jumped in the iteration sequence
@@ -306,9 +355,11 @@ int render_iteration(unsigned char* pbo, int iter) {
         L.wait_resolved = false;
     }
     const int mode = current_mode();
-    if (g.use_graph && !g_prof.on && !L.ws.stats) return replay_iteration(L, iter, mode);
-    L.expected_iter = -1;
-    return enqueue_iteration(L, iter, mode, false);
+    note_counts(L);
+    int rc;
+    if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
+    else { L.expected_iter = -1; rc = enqueue_iteration(L, iter, mode, false); }
+    return rc ? rc : request_counts(L);
 }
 
 // all lanes' work so far -> visible to lane 0's stream (event edges only, no host wait)
@@ -448,9 +499,9 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     return x + y * W;
 }
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 7) return PTK_E_BADARG;
+    if (which < 0 || which > 9) return PTK_E_BADARG;
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which != 4 && which != 5 && which != 6 && which != 7); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.seg_done = which == 7 ? nullptr : l.seg_done_mem; }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which < 4); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     return 0;

@@ -137,12 +137,13 @@ struct DevGeomMask { unsigned cube, sphere, diag, round; };   // round: spheres 
 // at a squared distance > (Rp + pr)^2 + QUAD2 * |o - c|^2, or the centre lies behind an origin that is outside that sphere.
 // QUAD2 covers the exact test's cancellation (3.6e-7 |o - c|^2) plus this test's own (2.4e-7): measured need 5e-7, shipped 40x.
 // (A sphere fills 52 % of its box: in cornell.txt the large sphere's box catches 50 % of the rays, the sphere 9-40 %.)
-struct DevMaterial {    // 16 dwords
+struct DevMaterial {    // 20 dwords
     int type;
     float albedo[3], albedo_s[3];
     float rough, metal, ior;     // constant-sampler rough/metal already clamped like Material::BSDF does (material.h:486-487)
     int albedo_tex, rough_tex, metal_tex, normal_tex;      // texture index per sampler, -1 = the constant above
-    float pad[2];
+    float albedo_pi[3];          // albedo_s / pi, the same IEEE fp32 division done once on the host (Lambertian bsdf, material.h:58)
+    float pad[3];
 };
 struct DevTex { int w, h; unsigned offset; int pad; };    // devTexObj (image.h:53-66): texels at texels[3 * (offset + y*w + x)]
 // One node of a direction-ordered threaded BVH, 32 B = two 16-B loads.  a/b encode the reference's (start,end,hit,miss):
@@ -708,12 +709,13 @@ PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3
 }
 
 // material parameters at a hit: the four devTexSampler::linearSample(uv) calls of material.h, resolved once
-struct MatEval { int type; f3 albedo_member, albedo; float rough, metal, ior; };
+struct MatEval { int type; f3 albedo_member, albedo, albedo_pi; float rough, metal, ior; };
 PTK_DI MatEval eval_material(const SceneView& S, const DevMaterial& m, f2 uv) {
     MatEval e;
     e.type = m.type; e.ior = m.ior;
     e.albedo_member = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
-    e.albedo = m.albedo_tex >= 0 ? tex_sample(S, m.albedo_tex, uv) : mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]);
+    if (m.albedo_tex >= 0) { e.albedo = tex_sample(S, m.albedo_tex, uv); e.albedo_pi = e.albedo / PTK_PI; }
+    else { e.albedo = mk3(m.albedo_s[0], m.albedo_s[1], m.albedo_s[2]); e.albedo_pi = mk3(m.albedo_pi[0], m.albedo_pi[1], m.albedo_pi[2]); }
     e.rough = m.rough_tex >= 0 ? gclamp(tex_sample(S, m.rough_tex, uv).x, PTK_ROUGHNESS_MIN, PTK_ROUGHNESS_MAX) : m.rough;
     e.metal = m.metal_tex >= 0 ? gclamp(tex_sample(S, m.metal_tex, uv).x, 0.f, 1.f) : m.metal;
     return e;
@@ -830,7 +832,7 @@ PTK_DI void scatter_sample(const MatEval& m, f3 n, f3 wo, Scatter& s, Rng& rng) 
     f3 albedo = m.albedo;
     switch (m.type) {
     case 0: {
-        s.bsdf = albedo / PTK_PI;
+        s.bsdf = m.albedo_pi;                                    // albedo / pi (material.h:58), divided once per material
         s.dir = sample_hemisphere_cosine(n, sample2D(rng));
         s.pdf = dot(s.dir, n) / PTK_PI;
         break; }
@@ -879,7 +881,7 @@ PTK_DI void scatter_sample(const MatEval& m, f3 n, f3 wo, Scatter& s, Rng& rng) 
 PTK_DI f3 mat_bsdf(const MatEval& m, f3 n, f3 wo, f3 wi) {       // Material::BSDF, material.h:483-501
     f3 albedo = m.albedo;
     switch (m.type) {
-    case 0: return albedo / PTK_PI;
+    case 0: return m.albedo_pi;
     case 3: return microfacet_bsdf(n, -1.f * wo, wi, albedo, m.rough);
     case 1: return metallic_bsdf(n, -1.f * wo, wi, albedo, m.rough, m.metal);
     default: return mk3(0, 0, 0);

@@ -80,6 +80,8 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
                                   PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce);
 int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img,
                         const Workspace& ws, hipStream_t st, bool last_bounce);
+int launch_tail(const SceneView& S, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
+                const Workspace& ws, hipStream_t st);
 void set_fused_block(int nt);
 void set_shade_bin(int nt);
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);

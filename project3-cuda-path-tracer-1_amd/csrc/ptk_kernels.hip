@@ -112,7 +112,8 @@ __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const
     constexpr int NW = NT / 64;
     constexpr int RB = NT == 512 ? 9 : 8;                 // bits of the ray index inside a list entry
     __shared__ float4 s_ray[2 * NT];                      // origin, direction
-    __shared__ float4 s_res[2 * NT];                      // winner's hit point, deferred normal
+    __shared__ float2 s_res[3 * NT];                      // winner's hit point + deferred normal, 24 B per ray (with 32 B the block's
+                                                          // static LDS crosses 160 KB / 6: five blocks per CU instead of six)
     __shared__ unsigned long long s_best[NT];
     __shared__ unsigned short s_list[NT * 16];
     __shared__ int s_cnt[NW];
@@ -167,8 +168,9 @@ __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const
                 }
                 __syncthreads();
                 if (key != ~0ull && s_best[r] == key) {
-                    s_res[2 * r] = make_float4(P.x, P.y, P.z, 0.f);
-                    s_res[2 * r + 1] = make_float4(NSv.x, NSv.y, NSv.z, 0.f);
+                    s_res[3 * r] = make_float2(P.x, P.y);
+                    s_res[3 * r + 1] = make_float2(P.z, NSv.x);
+                    s_res[3 * r + 2] = make_float2(NSv.y, NSv.z);
                 }
             }
             __syncthreads();
@@ -177,9 +179,9 @@ __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const
     a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0);
     const unsigned long long best = s_best[tid];
     if (best != ~0ull) {
-        const float4 p4 = s_res[2 * tid], n4 = s_res[2 * tid + 1];
+        const float2 r0 = s_res[3 * tid], r1 = s_res[3 * tid + 1], r2 = s_res[3 * tid + 2];
         a.t_min = __uint_as_float((unsigned)(best >> 32)); a.geom = (int)(unsigned)best;
-        a.P = mk3(p4.x, p4.y, p4.z); a.NS = mk3(n4.x, n4.y, n4.z);
+        a.P = mk3(r0.x, r0.y, r1.x); a.NS = mk3(r1.y, r2.x, r2.y);
     }
 }
 
@@ -1149,6 +1151,89 @@ __global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_tail: ALL remaining bounces of an iteration in ONE single-workgroup launch, for the sparse end of open scenes.
+// mis_test.txt at 1024x1024 depth 16 has 1 048 576 / 196 631 / 1 057 / 49 / 0 / 0 ... live paths per bounce: 12 of the 16
+// bounces are empty, yet each costs three full-capacity launches whose blocks only read the live count and leave
+// (36 of the 49 launches of an iteration).  The render loop therefore enqueues full-width bounces only while the live
+// count it has SEEN in earlier iterations is large (asynchronous read-back of counts[], no host wait — pathtrace.hip),
+// and finishes every iteration with this kernel: one block of 1024 threads that loops over the remaining bounces and, per
+// bounce, over chunks of 1024 paths — closest hit (the in-lane form, as pipeline 1), compacted slot through a block prefix
+// (order-preserving: still the reference's RNG key), shading, survivors written densely.  It is correct for ANY live
+// count (the prediction only decides how fast the tail is), writes the same counts[] / ray total / radiance as the
+// full-width kernels, and exits at the first bounce that has no path left.
+// ------------------------------------------------------------------------------------------------------------------
+#define PTK_TAIL_BLOCK 1024
+struct TailArgs {
+    int iter_arg; const int* iter_ptr; int depth0, trace_depth;
+    int* counts;                             // counts[d] = live paths entering bounce d (read at depth0, written above)
+    PtkPaths cur, nxt;                       // cur: the stream entering bounce depth0 (windowed if G.pref != null)
+    Gather G;
+    float* img; unsigned plane_stride; int spp, slot_bias;
+    unsigned long long* ray_total;
+    int* iter_advance; int iter_stride;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A) {
+    constexpr int NT = PTK_TAIL_BLOCK;
+    __shared__ DevMaterial s_mats[PTK_LDS_MATS];
+    const GeomStage gs = stage_geoms(S);
+    const MatTable mt = stage_materials<NT>(S, s_mats);
+    const int step = A.iter_ptr ? *A.iter_ptr : A.iter_arg;
+    const int iter = (step - 1) * A.spp + 1;
+    const Film img = {A.img, A.plane_stride};
+    PtkPaths cur = A.cur, nxt = A.nxt;
+    Gather G = A.G;
+    int n = A.counts[A.depth0];
+    for (int depth = A.depth0; depth < A.trace_depth; ++depth) {
+        if (n <= 0) {                                            // nothing left: the remaining bounces are empty
+            for (int d = depth + 1 + threadIdx.x; d <= A.trace_depth; d += NT) A.counts[d] = 0;
+            break;
+        }
+        int hits_before = 0, survivors = 0;
+        for (int c0 = 0; c0 < n; c0 += NT) {
+            const int i = c0 + threadIdx.x;
+            int flag = 0, alive = 0;
+            unsigned nv = 0, nt = 0;
+            Hit h;
+            PathRegs p;
+            h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
+            p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
+            if (i < n) {
+                const int src = gather_source(G, i / PTK_BLOCK, i, n);
+                const float4 o4 = ld4(cur.o_pix, src), d4 = ld4(cur.d_bnc, src), c4 = ld4(cur.col_pdf, src);
+                p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+                p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+                p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+                flag = closest_hit<false>(S, gs, p.o, p.d, h, nv, nt);
+                if (!flag && S.env_tex >= 0) add_radiance(img, p.pix, nan_to_zero(p.col * env_radiance(S, p.d)));   // pathtrace.cu:303-311
+            }
+            int total;
+            const int local = block_excl_prefix_n<NT>(flag, total);
+            if (flag) alive = shade_path<MODE>(S, gs, mt, iter, hits_before + local + A.slot_bias, depth, h, p, img);
+            int total2;
+            const int local2 = block_excl_prefix_n<NT>(alive, total2);
+            if (alive) {
+                const int s = survivors + local2;
+                st4(nxt.o_pix, s, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+                st4(nxt.d_bnc, s, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+                st4(nxt.col_pdf, s, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+            }
+            hits_before += total; survivors += total2;
+        }
+        if (threadIdx.x == 0) {
+            A.counts[depth + 1] = survivors;
+            if (A.ray_total) atomicAdd(A.ray_total, (unsigned long long)n);
+        }
+        __syncthreads();                                         // this bounce's stores are visible to the whole workgroup before the next bounce reads them
+        const PtkPaths t = cur; cur = nxt; nxt = t;
+        G.pref = nullptr; G.first = nullptr; G.src = nullptr;   // survivors were written densely
+        n = survivors;
+    }
+    if (threadIdx.x == 0 && A.iter_advance) *A.iter_advance += A.iter_stride;
+}
+
 // stand-alone form of segments_block (one block; used when the shading kernel does not run the tail itself)
 #define PTK_SEG_BLOCK 1024
 __global__ void __launch_bounds__(PTK_SEG_BLOCK) k_segments(int n_arg, const int* __restrict__ d_n, const int* __restrict__ agg, int* __restrict__ pref,
@@ -1386,6 +1471,24 @@ int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int c
     case PTK_MODE_MIS: return launch_fused_mode<PTK_MODE_MIS>(S, A, capacity, ws.stats != nullptr, st);
     default: return PTK_E_BADARG;
     }
+}
+// all bounces from `depth0` on in one single-workgroup launch (k_tail); cur = the stream entering bounce depth0
+int launch_tail(const SceneView& S, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
+                const Workspace& ws, hipStream_t st) {
+    TailArgs A;
+    A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth0 = depth0; A.trace_depth = trace_depth;
+    A.counts = ws.counts; A.cur = cur; A.nxt = nxt;
+    const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
+    A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
+    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
+    A.ray_total = ws.ray_total; A.iter_advance = ws.iter_dev; A.iter_stride = ws.iter_stride;
+    switch (mode) {
+    case PTK_MODE_BSDF: k_tail<PTK_MODE_BSDF><<<1, PTK_TAIL_BLOCK, stage_bytes(S), st>>>(S, A); break;
+    case PTK_MODE_DIRECTLI: k_tail<PTK_MODE_DIRECTLI><<<1, PTK_TAIL_BLOCK, stage_bytes(S), st>>>(S, A); break;
+    case PTK_MODE_MIS: k_tail<PTK_MODE_MIS><<<1, PTK_TAIL_BLOCK, stage_bytes(S), st>>>(S, A); break;
+    default: return PTK_E_BADARG;
+    }
+    return launch_rc();
 }
 void set_fused_block(int nt) { g_fused_block = (nt == 512) ? 512 : 256; }
 bool g_light_fix = false;

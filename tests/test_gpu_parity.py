@@ -174,13 +174,13 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("pipeline", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
     """ptk_set_pipeline variants (1 = staged kernels with the BVH walked inside the intersect kernel, 2 = the same with wave-uniform
     loops over every analytic primitive instead of the staged candidate loops, 3 = the fused bounce kernel with chained scans,
     4 = staged intersect + shading that compacts its survivors through one chained scan, 5 = default pipeline with the work-list
-    rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree with four lanes per ray, 7 = default pipeline with the
-    window bookkeeping in a separate k_segments launch instead of the shading kernel's last block)
+    rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree with four lanes per ray, 7 / 8 = default pipeline with the
+    window bookkeeping in a separate k_segments launch / in the shading kernel's last block, 9 = every bounce at full width (no k_tail))
     produce exactly the oracle's results."""
     for name, res, depth, mode in (("bunny_cornell.txt", (128, 128), 5, "MIS"), ("obj_test.txt", (64, 64), 4, "BSDF"), ("cornell.txt", (96, 96), 4, "BSDF")):
         m = MODES[mode]
@@ -215,6 +215,34 @@ def test_wide_walk_equals_threaded_walk_full_size(ptk, torch_cuda, name, mode):
     for lanes in (1, 3):
         assert np.array_equal(out[(5, lanes)][1], out[(6, lanes)][1])
         assert np.array_equal(out[(5, lanes)][0], out[(6, lanes)][0]), int((out[(5, lanes)][0] != out[(6, lanes)][0]).any(axis=1).sum())
+
+
+@pytest.mark.parametrize("name,res,depth,mode,lanes", [("mis_test.txt", (512, 512), 16, "MIS", 1), ("mis_test.txt", (512, 512), 16, "BSDF", 3),
+                                                       ("mis_test2.txt", (256, 256), 12, "DIRECT", 1), ("bunny_cornell.txt", (40, 40), 10, "MIS", 1),
+                                                       ("cornell.txt", (24, 24), 8, "BSDF", 3)])
+def test_sparse_tail(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
+    """k_tail: once earlier iterations have shown that only a few paths survive a bounce, the rest of every iteration runs in one
+    single-workgroup launch.  The switch happens a few iterations in (asynchronous read-back of the live counts), so twelve
+    iterations cover both regimes; tiny frames put whole iterations in the tail (also with the BVH walk and shadow rays in it).
+    Live counts of every iteration and the image == oracle, bit for bit, with one and three iterations in flight."""
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    rays = 0
+    for it in range(1, 13):
+        r.iterate(it)
+        rr, live = o.pathtrace(m, it, planes[(it - 1) % lanes]); rays += rr
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (it, counts, live)
+    ref = planes[0].copy()
+    for p in planes[1:]:
+        ref = ref + p
+    img = r.image()
+    assert r.ray_total() == rays
+    r.close()
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
 
 def test_intersect_edge_rays(ptk, orc, torch_cuda):
