@@ -166,6 +166,20 @@ def pmc_record(scene_file):
         return None
 
 
+def rocprof_avg_us(scene_file, kernel_substr):
+    """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of the single-stream configuration
+    (profiles/r2_<scene>_kernel_stats_inflight1.csv, produced by tools/refresh_profiles.sh with `bench.py --in-flight 1 --graph 0`)"""
+    import csv
+    try:
+        f = os.path.join(ROOT, "profiles", "r2_%s_kernel_stats_inflight1.csv" % (scene_file or "").replace(".txt", ""))
+        for row in csv.DictReader(open(f)):
+            if kernel_substr in row["Name"]:
+                return float(row["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
+
+
 def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_file=None):
     ms_int, _ = prof["intersect"]
     has_bvh = scene.n_triangles > 0
@@ -175,6 +189,7 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
     pmc = pmc_record(scene_file) if (scene.width, scene.height) == (800, 800) else None
     traffic = pmc["traffic_bytes_per_launch"] if pmc else None
     avg_us = 1e3 * ms_int / (steps * live_launches)
+    rp_us = rocprof_avg_us(scene_file, "k_intersect<false, false>") if (scene.width, scene.height) == (800, 800) else None
     hbm = {"achieved_hbm": round(traffic / (avg_us * 1e-6) / 1e9, 1), "frac_hbm": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
            "achieved_hbm_note": "PMC traffic / this run's average launch time: the rate the HBM really sees (node / triangle re-reads of a "
                                 "BVH scene are served by L2); `achieved` is the ALGORITHMIC rate at the reference's struct sizes (SURVEY 8d)"} if traffic else {}
@@ -184,6 +199,11 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE, **hbm,
         "counters": (pmc or {}).get("counters"),
+        **({"avg_launch_us_rocprof": round(rp_us, 2), "frac_rocprof": round(bytes_per_ray * rays_p / (steps * live_launches) / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+            "rocprof_note": "k_intersect's average duration in the committed rocprofv3 summary of the same single-stream configuration "
+                            "(profiles/r2_%s_kernel_stats_inflight1.csv); the live HIP-event figure above brackets every launch with two event "
+                            "records and so includes ~3 us of dispatch / event latency per launch" % (scene_file or "").replace(".txt", "")}
+           if (rp_us and not has_bvh) else {}),
         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_p / (steps * live_launches)),
         "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / (steps * live_launches), 1),
         "avg_launch_us": round(avg_us, 2),

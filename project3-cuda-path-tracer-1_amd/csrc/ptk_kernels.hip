@@ -385,14 +385,19 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
 //   * two ballots give the quad its 8-bit hit mask; a hit child's position among the hit children in the ray's visiting
 //     order is popc(hits & before[dir]) (the node stores, per direction tree, which children precede each child), so all
 //     hit children are pushed at once, in reverse visiting order, without a loop;
-//   * per-ray stack in LDS; the first PTK_WIDE_TOP nodes of the breadth-first node array (the top 3-4 levels) are staged
+//   * per-ray stack in LDS; the first PTK_WIDE_TOP nodes of the breadth-first node array (the top two levels) are staged
 //     in LDS once per block;
 //   * leaves run the reference's exact box test, the `tEnter > t_min` cut and the Moeller-Trumbore test (same functions
 //     as the threaded walk), redundantly in the four lanes.
 // Rays with a zero / denormal direction component (Bounds3.hpp:174-177 containment tests) and rays whose stack would
 // overflow take the threaded walk instead — same result by construction.
 // ------------------------------------------------------------------------------------------------------------------
-#define PTK_WIDE_TOP 128          // wide nodes staged in LDS (18 KB)
+// wide nodes staged in LDS per block (the root and the first nodes of the breadth-first array).  A block serves only 64 rays, so the
+// copy is not free: measured on the bunny scene (intersect stage, ms per iteration) 1: 0.882, 8: 0.880, 16: 0.877, 64: 0.883,
+// 128: 0.926, 256: 1.150 — the upper levels are served by L1/L2 just as well; two levels (2.3 KB) is what pays.
+#ifndef PTK_WIDE_TOP
+#define PTK_WIDE_TOP 16
+#endif
 #define PTK_WIDE_STACK 24         // stack entries per ray
 #define PTK_WIDE_STRIDE 25        // odd: the 16 rays of a wave spread over the LDS banks
 #define PTK_WIDE_RAYS (PTK_BLOCK / 4)
