@@ -213,7 +213,13 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *   3 = fused: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans with
  *       ticketed block ids; the hit record never leaves registers).  Least memory traffic, but the ticket counter
  *       serialises block starts (~11 ns each): slower than 0 on MI355X at the BASELINE sizes;
- *   4 = like 0 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables. */
+ *   4 = like 0 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables;
+ *   5 = like 0, the work-list rays walk the reference's threaded 6-direction BVH, one ray per lane (0 walks the 8-wide
+ *       collapsed form of the same tree, four lanes per ray, csrc/wide_bvh.h); 6 = the wide walk, explicitly;
+ *   7 / 8 = like 0 with the window bookkeeping in a separate one-block k_segments launch / in the last block of the
+ *       shading kernel (0 picks 8 with several iterations in flight, 7 with one);
+ *   9 = like 0, every bounce launched at full width (0 finishes the sparse end of an iteration in one single-workgroup
+ *       k_tail launch once earlier iterations have shown that few paths survive). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 

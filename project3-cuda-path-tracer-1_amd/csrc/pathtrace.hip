@@ -114,10 +114,9 @@ int context_free() {
     return 0;
 }
 
-// BVH walk of the work-list rays (bit-identical hits either way, ptk_internal.h): pipeline 5 / 6 force the threaded / the
-// wide walk; otherwise the wide walk (shortest dependent chain) when one iteration runs at a time, and the threaded walk
-// (fewest instructions) when several iterations in flight keep the machine full.  Measured on the bunny scene, Grays/s:
-// 1 in flight 2.42 threaded / 2.86 wide; 3 in flight 4.90 / 4.34.
+// BVH walk of the work-list rays (bit-identical hits either way, ptk_internal.h): the wide walk unless pipeline 5 asks for the
+// reference's threaded walk.  Measured on the bunny scene, Grays/s, threaded / wide: one iteration at a time 2.47 / 3.28; three in
+// flight 4.99 / 5.38 (with 128 staged nodes the wide walk's 25 KB of LDS per block lost there, 4.34; with 16 it does not).
 // Window bookkeeping of the segmented streams: by the shading kernel's last block (pipeline 8, default with several iterations in
 // flight: one launch less per bounce, +2 % on the headline) or by a separate one-block k_segments launch (pipeline 7, default with
 // one iteration at a time, where the serial tail of that last block costs more than the launch: 0.352 vs 0.363 ms per iteration).
@@ -127,9 +126,8 @@ static bool fold_segments(int pipeline, int n_lanes) {
     return n_lanes > 1;
 }
 static int pick_walk(int pipeline, int n_lanes) {
-    if (pipeline == 5) return PTK_WALK_THREADED;
-    if (pipeline == 6) return PTK_WALK_WIDE;
-    return n_lanes > 1 ? PTK_WALK_THREADED : PTK_WALK_WIDE;
+    (void)n_lanes;
+    return pipeline == 5 ? PTK_WALK_THREADED : PTK_WALK_WIDE;
 }
 
 int lane_init(Lane& l, int idx) {

@@ -13,8 +13,7 @@ struct PtkScene {
 namespace ptk {
 
 // BVH walk of the work-list rays (both give bit-identical hits): the reference's threaded walk, one ray per lane (fewest
-// instructions: best when several iterations in flight fill the machine); four lanes per ray over the 8-wide collapsed tree
-// (shortest dependent chain: best with one iteration in flight).  AUTO picks by the number of iterations in flight.
+// instructions, longest dependent chain); four lanes per ray over the 8-wide collapsed tree (default).
 enum { PTK_WALK_AUTO = 0, PTK_WALK_THREADED = 1, PTK_WALK_WIDE = 2 };
 
 void set_light_fix(bool on);            // opt-in fixed cube lights (ptk_set_light_fix)
