@@ -375,6 +375,21 @@ def main():
         }
         if multi is not None:
             out["multi_gpu"] = multi
+        if N == 1:
+            # how busy the vector ALUs are over the TIMED region: VALU-active cycles of every kernel of one iteration (committed
+            # single-stream PMC pass, SQ_ACTIVE_INST_VALU in quad-cycles) / (1024 SIMDs x wall cycles of one step at the 2.39 GHz
+            # rocm-smi shows during this run).  With iterations in flight the kernels overlap; their instruction counts do not change.
+            rec = pmc_record(a.scene) if (scene.width, scene.height) == (800, 800) and res is None and a.depth < 0 else None
+            if rec:
+                per_iter = 0.0
+                for k, e in rec.items():
+                    c = e.get("counters") if isinstance(e, dict) else None
+                    if c and "SQ_ACTIVE_INST_VALU" in c and k != "counters":
+                        per_iter += c["SQ_ACTIVE_INST_VALU"] * (1 if k == "k_generate" else scene.trace_depth)
+                cyc = 4.0 * per_iter / 1024.0
+                out["valu_busy_estimate"] = {"frac": round(cyc / (1e-3 * out["ms_per_step"] * 2.39e9), 3), "valu_active_cycles_per_simd_per_step": round(cyc),
+                                             "clock_GHz_assumed": 2.39, "source": PMC_FILE,
+                                             "note": "the timed configuration is bound by vector-ALU issue, not by HBM: see roofline.counters and DESIGN.md section 5"}
         out.update(extra)
         print(json.dumps(out))
     if N > 1:
