@@ -1503,7 +1503,7 @@ OrcScene* orc_scene_load(const char* file, int res_w, int res_h, int depth) {
     setDevData(*S);
     return S;
 }
-void orc_scene_free(OrcScene* S) { delete S; }
+void orc_scene_free(OrcScene* S) { if (g_tex_scene == S) g_tex_scene = nullptr; delete S; }     // never leave the samplers a dangling scene
 const char* orc_scene_error(OrcScene* S) { return S->error.c_str(); }
 
 // counts: [0]=geoms [1]=materials [2]=triangles [3]=bvh_size [4]=lights [5]=traceDepth [6]=iterations [7]=res.x [8]=res.y
@@ -1582,12 +1582,14 @@ void orc_make_geom(int type, int materialid, const float* tr, const float* rot, 
 // scatterSample probe: material (10 dwords), n[3], wo[3], uv ignored; rng key; out: dir[3], bsdf[3], pdf
 void orc_scatter_sample(const void* mat, const float* n, const float* wo, int iter, int idx, int depth, float* out) {
     Isect is = Isect(); is.n = v3(n[0], n[1], n[2]); is.t = 1;
+    g_tex_scene = nullptr;                       // a bare material record: constant samplers only
     Rng rng = make_rng(iter, idx, depth);
     ScatterRec s; scatterSample(*(const Material*)mat, is, v3(wo[0], wo[1], wo[2]), s, rng);
     out[0] = s.dir.x; out[1] = s.dir.y; out[2] = s.dir.z; out[3] = s.bsdf.x; out[4] = s.bsdf.y; out[5] = s.bsdf.z; out[6] = s.pdf;
 }
 void orc_mat_bsdf_pdf(const void* mat, const float* n, const float* wo, const float* wi, float* out) {
     Isect is = Isect(); is.n = v3(n[0], n[1], n[2]);
+    g_tex_scene = nullptr;
     v3 f = matBSDF(*(const Material*)mat, is, v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]));
     out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = matPDF(*(const Material*)mat, is, v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]));
 }
