@@ -245,6 +245,23 @@ def test_sparse_tail(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
     assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
 
+def test_sparse_tail_with_partition_and_batches(ptk, orc, torch_cuda):
+    """k_tail under the multi-GPU configuration of bench.py: rank 1 of a 2-way tile partition tracing 2 samples per launch (so the
+    RNG keys carry the rank offset and the sample planes), open scene, twelve launches == the oracle's runs of the same part."""
+    name, res, depth, part, spp = "mis_test.txt", (256, 256), 12, (2, 1, 8), 2
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, ptk.MODE_MIS, partition=part, spp=spp)
+    planes = np.zeros((spp, o.P, 3), np.float32)
+    for step in range(1, 13):
+        r.iterate(step)
+        _, live = o.pathtrace_batch(ptk.MODE_MIS, step, spp, planes, partition=part)
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (step, counts, live)
+    img = r.image(); r.close()
+    assert np.array_equal(img, planes[0] + planes[1])
+
+
 def test_intersect_edge_rays(ptk, orc, torch_cuda):
     """Hand-made rays through ptk_intersect: axis-parallel directions (zero components take the containment branch of
     Bounds3::IntersectP, Bounds3.hpp:174-177, and divide-by-zero slabs in the box test), origins inside primitives, rays that
