@@ -2,14 +2,15 @@
 //
 // Reference kernel (src/pathtrace.cu) -> kernels here:
 //   generateRayFromCamera (135-163)                       -> k_generate
-//   computeIntersections  (169-346)                       -> k_intersect (+ k_list, k_traverse, k_finalize for scenes with triangles)
+//   computeIntersections  (169-346)                       -> k_intersect (+ k_list, k_traverse_wide | k_traverse, k_finalize for scenes with triangles)
 //   PTkernel / DirectLiPTkernel / MisPTkernel (348-588)   -> k_shade_binned<M> (render pipeline), k_shade<M> (kernel-level ABI)
 //   compact_rays (614-631; thrust scan + 2x scatter_if + 2 blocking D2H), twice per bounce
 //                                                         -> nothing moves: virtual compaction of the hits + block-local compaction
-//                                                            of the survivors + k_segments (window tables); k_count + k_scatter
+//                                                            of the survivors + segments_tail / k_segments (window tables); k_count + k_scatter
 //                                                            remain as the stand-alone stable compaction (ptk_compact, pipeline 4)
 //   sendImageToPBO (32-65)                                -> k_tonemap
 //   (whole bounce in one launch, A/B only)                -> k_bounce (pipeline 3)
+//   (the sparse end of an iteration in one launch)        -> k_tail
 // What is specific to MI355X:
 //   * 256-thread blocks = 4 wave64; all state streams are float4 SoA (16 B/lane, 1 KiB per wave access);
 //   * scene constants are read with wave-uniform indices through the constant address space -> scalar loads / SGPR operands;
