@@ -272,7 +272,7 @@ PTK_DI f3 xform_nrm_d(const float* m, f3 v, int diag) {
 // Staged form: kernels copy dwords [2, 26) of every DevGeom into LDS once per block (stage_geoms), 24 floats = 96 B per
 // primitive, and each lane fetches the record of ITS current candidate with six ds_read_b128.
 struct GeomXf { float inv[12], fwd[12]; int diag; };
-#define PTK_XF_FLOATS 24
+#define PTK_XF_FLOATS 36            // staged record: inv[12], fwd[12], invT[9], diag, materialid, pad (ptk_kernels.hip: stage_geoms)
 #define PTK_LDS_GEOMS_MAX 512          // 48 KB of LDS; larger scenes use the wave-uniform loops
 struct GeomStage { const float* xf; bool on; };
 // the same record by reference: the exact tests read inv / fwd from LDS where they use them (fwd only on a hit), which keeps
@@ -568,6 +568,14 @@ PTK_DI void analytic_record(const SceneView& S, const Analytic& a, Hit& h) {
     h.n = normalize(analytic_normal(S.geoms[a.geom], a.NS));     // per-lane geom index: one gather, once per ray
     h.uv.x = 0.f; h.uv.y = 0.f;
     h.mat = S.geoms[a.geom].materialid; h.geom = a.geom; h.tri = -1;
+}
+// the same from the LDS-staged records (no dependent global gather at the end of the kernel)
+PTK_DI void analytic_record_staged(const float* xf, const Analytic& a, Hit& h) {
+    const float* r = xf + (size_t)a.geom * PTK_XF_FLOATS;
+    h.t = a.t_min; h.p = a.P;
+    h.n = normalize(normalize(xform_nrm_d(r + 24, a.NS, __float_as_int(r[33]))));
+    h.uv.x = 0.f; h.uv.y = 0.f;
+    h.mat = __float_as_int(r[34]); h.geom = a.geom; h.tri = -1;
 }
 // (2) one traversal state per ray: threaded (stackless) walk over the direction-ordered nodes (pathtrace.cu:236-279)
 struct Walk { f3 o, d, inv; float t_min; int tri; float u, v; int idx; const DevNode* nodes; bool general; };

@@ -29,6 +29,23 @@ using namespace ptk;
 #define PTK_BLOCK 256
 #define PTK_WAVES (PTK_BLOCK / 64)
 
+// Diagnostic build only (make EXTRA_HIPFLAGS=-DPTK_PHASE_TIMING, tools/diag/phase_timing.py): where a wave of k_intersect /
+// k_shade_binned spends its LIFETIME — s_memtime stamps at phase boundaries (with s_waitcnt(0), so phases that would overlap are
+// serialised: upper bounds), added into a per-wave slot with plain stores; one stream only.  Off in the product.
+#ifdef PTK_PHASE_TIMING
+#define PTK_PHASE_SLOTS 16384
+__device__ unsigned long long g_phase_buf[2][PTK_PHASE_SLOTS][8];      // per kernel, per wave slot: cycles per phase ([7] = visits)
+#define PTK_PHASE_BEGIN() unsigned long long ph_prev = __builtin_amdgcn_s_memtime(); int ph_k = 0; \
+    const unsigned ph_slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % PTK_PHASE_SLOTS
+#define PTK_PHASE(K) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) g_phase_buf[K][ph_slot][ph_k] += ph_now - ph_prev; ph_prev = __builtin_amdgcn_s_memtime(); ++ph_k; } while (0)
+#define PTK_PHASE_END(K) do { if ((threadIdx.x & 63) == 0) g_phase_buf[K][ph_slot][7] += 1ull; } while (0)
+#else
+#define PTK_PHASE_BEGIN() do {} while (0)
+#define PTK_PHASE(K) do {} while (0)
+#define PTK_PHASE_END(K) do {} while (0)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -212,8 +229,9 @@ __device__ __forceinline__ int gather_source(const Gather& G, int b, int i, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Block-cooperative copy of every primitive's inverseTransform / transform rows (dwords [2, 26) of DevGeom) into dynamic
-// LDS; must be reached by all threads of the block.  The launchers size the dynamic LDS with stage_bytes(S).
+// Block-cooperative copy of every primitive's record into dynamic LDS as {inverseTransform rows, transform rows, invTranspose,
+// diag, materialid, pad} (dwords [2, 36) and 1 of DevGeom: the matrices stay 16-byte aligned); must be reached by all threads of the
+// block.  The launchers size the dynamic LDS with stage_bytes(S).
 extern __shared__ float4 ptk_dyn_lds[];
 __device__ __forceinline__ GeomStage stage_geoms(const SceneView& S) {
     GeomStage gs;
@@ -225,7 +243,7 @@ __device__ __forceinline__ GeomStage stage_geoms(const SceneView& S) {
         const int total = S.n_geoms * PTK_XF_FLOATS;
         for (int j = threadIdx.x; j < total; j += blockDim.x) {
             const int g = j / PTK_XF_FLOATS, k = j - g * PTK_XF_FLOATS;
-            dst[j] = src[(size_t)g * (sizeof(DevGeom) / 4) + 2 + k];
+            dst[j] = src[(size_t)g * (sizeof(DevGeom) / 4) + (k < 34 ? 2 + k : (k == 34 ? 1 : 0))];
         }
         __syncthreads();
     }
@@ -265,8 +283,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     if (i == 0 && ray_total) atomicAdd(ray_total, (unsigned long long)n);
+    PTK_PHASE_BEGIN();
     const int src = gather_source(G, b, i, n);
+    PTK_PHASE(0);                                    // 0: live count + window tables
     const GeomStage gs = stage_geoms(S);
+    PTK_PHASE(0);                                    // 1: primitive records -> LDS
     int flag = 0;
     bool heavy = false;
     unsigned nv = 0, nt = 0;
@@ -277,19 +298,25 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
         ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
         if (G.src) G.src[i] = src;
     }
+    PTK_PHASE(0);                                    // 2: ray loads
     Analytic a;
     if (gs.on) analytic_closest_block<PTK_BLOCK>(S, gs, active, ro, rd, a);          // block-cooperative: every thread takes part
     else if (active) analytic_closest(S, gs, ro, rd, a);
+    PTK_PHASE(0);                                    // 3: candidates + pair lists + exact tests
     if (active) {
         Hit h;
         if (SPLIT) {
             flag = a.geom >= 0;
-            if (flag) analytic_record(S, a, h);
+            if (flag) { if (gs.on) analytic_record_staged(gs.xf, a, h); else analytic_record(S, a, h); }
             // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
             const DevNode root = S.nodes[(size_t)mtbvh_dir(rd) * S.bvh_size];
             float tEnter;
             heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
             if (STATS && !heavy) nv = 1;
+        } else if (gs.on && S.n_tris == 0) {          // analytic-only scene (the empty BVH root cannot hit): record from the staged tables
+            flag = a.geom >= 0;
+            if (flag) analytic_record_staged(gs.xf, a, h); else h.t = -1.0f;
+            if (STATS) nv = 1;                          // the reference still visits the empty root once
         } else {
             flag = closest_hit_finish<STATS>(S, a, ro, rd, h, nv, nt);
         }
@@ -302,6 +329,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
         }
         valid[i] = flag;
     }
+    PTK_PHASE(0);                                    // 4: hit record + stores
     if (SPLIT) {                                    // flag the rays that entered the root box; k_list compacts them into a work list
         if (i < n) heavy_flag[i] = heavy ? 1 : 0;
         int total;
@@ -313,6 +341,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
         (void)block_excl_prefix(flag, total);
         if (threadIdx.x == 0) agg[b] = total;
     }
+    PTK_PHASE(0);                                    // 5: block aggregates
+    PTK_PHASE_END(0);
     if (STATS && stats) {
         unsigned long long a = nv, c = nt;
 #pragma unroll
@@ -836,25 +866,38 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
         if (n <= 0 && b == 0 && seg_tail.done) segments_block<NT, false>(0, agg_b, seg_tail.pref, seg_tail.first, seg_tail.count_out, seg_tail.iter_advance, seg_tail.iter_stride);
         return;
     }
+    PTK_PHASE_BEGIN();
     GeomStage gs; gs.xf = nullptr; gs.on = false;
     if (MODE != PTK_MODE_BSDF) gs = stage_geoms(S);
     __shared__ DevMaterial s_mats[PTK_LDS_MATS];
     const MatTable mt = stage_materials<NT>(S, s_mats);
+    PTK_PHASE(1);                                    // 0: staging
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // --- original order: flag, compacted slot, material key
     const int flag = (i < n) ? valid_a[i] : 0;
     __shared__ int s_src[NT];
     s_src[tid] = (srcidx && i < n) ? srcidx[i] : i;          // physical slot of this dense position, handed to whoever shades it
+    // the hit's material id is loaded beside the flag, not behind it (one dependent global latency less at the head of the kernel);
+    // for a miss the word is stale or never written — it is not used then
+    const int mat_word = (i < n) ? __float_as_int(hits.p_mat[4 * (size_t)i + 3]) : 0;
     int key = NKEY - 1;
-    if (flag) key = fetch_material_type(S, mt, __float_as_int(hits.p_mat[4 * (size_t)i + 3]));
+    if (flag) key = fetch_material_type(S, mt, mat_word);
     unsigned long long bal[NKEY];
 #pragma unroll
     for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
     if (lane < NKEY) s_cnt[wid][lane] = __popcll(bal[lane]);
     // prior hit count of all earlier 256-path ranges (agg_a is indexed by 256-path range)
+    // (16-byte loads, four passes in flight: with one 4-byte load per pass the head of the kernel waited up to ten L2 latencies in a row)
     int prior = 0;
-    for (int k = tid; k < b * SUB; k += NT) prior += agg_a[k];
+    {
+        const int B = b * SUB, B4 = B & ~3;
+        int4 acc = make_int4(0, 0, 0, 0);
+#pragma unroll 4
+        for (int k = 4 * tid; k < B4; k += 4 * NT) { const int4 v = *reinterpret_cast<const int4*>(agg_a + k); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        prior = (acc.x + acc.y) + (acc.z + acc.w);
+        if (tid < B - B4) prior += agg_a[B4 + tid];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o, 64);
     if (lane == 0) s_red[wid] = prior;
@@ -876,6 +919,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
     s_perm[rank] = tid;
     s_slot[tid] = prior + hits_before + slot_bias;      // slot_bias: rank-unique RNG keys under the tile partition (0 on one GPU)
     __syncthreads();
+    PTK_PHASE(1);                                    // 1: flags, slot, counting sort
     // --- sorted order: thread `tid` shades item src
     int alive = 0, src = -1;
     PathRegs p;
@@ -901,6 +945,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
             st4(paths.col_pdf, ps, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
         }
     }
+    PTK_PHASE(1);                                    // 2: loads + shading
     __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
     s_slot[tid] = 0;
     __syncthreads();
@@ -923,8 +968,11 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
             st4(seg_out.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
             st4(seg_out.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
         }
+        PTK_PHASE(1);                                // 3: survivor compaction + stores
         if (seg_tail.done) segments_tail<NT>(seg_tail, n, b, total, agg_b);       // the last block to get here finishes the bounce
         else if (tid == 0) agg_b[b] = total;
+        PTK_PHASE(1);                                // 4: segment bookkeeping (the last block does the work)
+        PTK_PHASE_END(1);
         return;
     }
     if (tid < SUB && (b * SUB + tid) * PTK_BLOCK < n) {
@@ -1583,5 +1631,18 @@ int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char*
     k_tonemap<<<grid_for(P), PTK_BLOCK, 0, (hipStream_t)stream>>>(img, P, iter, reinterpret_cast<uchar4*>(pbo));
     return launch_rc();
 }
+
+#ifdef PTK_PHASE_TIMING
+/* diagnostic build only: out[2][8] = cycles per phase summed over all waves ([7] = wave visits) for k_intersect (0) and
+ * k_shade_binned (1); clears the buffer */
+int ptk_debug_phases(unsigned long long* out) {
+    static unsigned long long host[2][PTK_PHASE_SLOTS][8];
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_buf), sizeof(host)) != hipSuccess) return 1;
+    for (int k = 0; k < 2; ++k) for (int j = 0; j < 8; ++j) { unsigned long long t = 0; for (int w = 0; w < PTK_PHASE_SLOTS; ++w) t += host[k][w][j]; out[k * 8 + j] = t; }
+    for (int k = 0; k < 2; ++k) for (int w = 0; w < PTK_PHASE_SLOTS; ++w) for (int j = 0; j < 8; ++j) host[k][w][j] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_buf), host, sizeof(host)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 } // extern "C"
