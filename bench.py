@@ -5,7 +5,10 @@
 
 Metric (BASELINE.json): Mrays/s = (sum over iterations and bounces of live paths entering the intersection stage) /
 wall time of the pathtrace() calls, on scenes/cornell.txt, 800x800, depth 8 (configs[1]; SampleMode BSDF).
-A "step" is one pathtrace() iteration (one sample per pixel) of the whole frame.
+A "step" is one batch of `--iters-per-step` (default 16) consecutive pathtrace() iterations of the whole frame, i.e. 16 samples
+per pixel: the reference renders thousands of iterations per image (its gallery: 20 and 2000), and with iterations in flight a
+handful of iterations would mostly time the fill and drain of the pipeline (measured: 64 iterations 16.8, 256 18.1, 1024
+18.3 Grays/s).  `ms_per_iteration` is on the line beside `ms_per_step`.
 
 N = 1 : one process, the full frame, one sample per pixel per step.
 N > 1 : launched by torch.distributed.run, one rank per GPU.  The frame is sharded into interleaved row tiles
@@ -46,6 +49,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--iters-per-step", type=int, default=16,
+                    help="pathtrace() iterations (samples per pixel of the whole frame) in one step: a step is one batch of this many iterations")
     ap.add_argument("--scene", default="cornell.txt")
     ap.add_argument("--res", type=int, nargs=2, default=None)
     ap.add_argument("--depth", type=int, default=-1)
@@ -262,7 +267,8 @@ def main():
             h = red.cpu(); dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
 
     it = 0
-    for _ in range(a.warmup):
+    IPS = max(1, a.iters_per_step)
+    for _ in range(a.warmup * IPS):
         it += 1; r.iterate(it)
     if N > 1:                      # warm the communicator outside the timed region
         reduce_radiance()
@@ -271,7 +277,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     r.timer_start()
-    for _ in range(a.steps):
+    for _ in range(a.steps * IPS):
         it += 1; r.iterate(it)
     dev_ms = r.timer_stop()
     if N > 1:
@@ -292,11 +298,11 @@ def main():
         other_spp = 1 if weak else N
         r2 = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), spp=other_spp)
         r_saved, r = r, r2
-        for i in range(1, a.warmup + 1):
+        for i in range(1, a.warmup * IPS + 1):
             r.iterate(i)
         barrier(); q0 = r.ray_total(); barrier()
         tt0 = time.perf_counter()
-        for i in range(a.warmup + 1, a.warmup + 1 + a.steps):
+        for i in range(a.warmup * IPS + 1, (a.warmup + a.steps) * IPS + 1):
             r.iterate(i)
         reduce_radiance()
         barrier()
@@ -331,7 +337,7 @@ def main():
             for i in range(1, 5):
                 rb.iterate(i)
             rb.sync(); rb0 = rb.ray_total(); rb.timer_start()
-            for i in range(5, 5 + 24):
+            for i in range(5, 5 + 128):
                 rb.iterate(i)
             bms = rb.timer_stop(); brays = rb.ray_total() - rb0
             rb.close()
@@ -343,14 +349,14 @@ def main():
             # the reference's own schedule: one iteration at a time, eager launches -> its float accumulation order exactly
             # (the headline overlaps `in_flight` iterations: image = ((p0 + p1) + p2), each iteration itself unchanged)
             rr = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=1, graph=False)
-            for i in range(1, a.warmup + 1):
+            for i in range(1, a.warmup * IPS + 1):
                 rr.iterate(i)
             rr.sync(); q0 = rr.ray_total(); tt0 = time.perf_counter()
-            for i in range(a.warmup + 1, a.warmup + 1 + a.steps):
+            for i in range(a.warmup * IPS + 1, (a.warmup + a.steps) * IPS + 1):
                 rr.iterate(i)
             rr.sync(); tt = time.perf_counter() - tt0; qr = rr.ray_total() - q0
             rr.close()
-            ref_order = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(1e3 * tt / a.steps, 4),
+            ref_order = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(1e3 * tt / a.steps, 4), "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
                          "config": "iterations_in_flight 1, graph_replay false: the reference's accumulation order, bit-identical image"}
         cpu = None
         if N == 1 and a.cpu_seconds > 0:
@@ -362,12 +368,12 @@ def main():
             "data": f"the reference's own scene file scenes/{a.scene} (verbatim copy, parsed by this build's loader); no synthetic inputs, no dataset",
             "config": {"workload": f"scenes/{a.scene} {scene.width}x{scene.height} depth {scene.trace_depth}, SampleMode {a.mode.upper()}"
                                    + (" (BASELINE configs[1])" if a.scene == "cornell.txt" and res is None and a.depth < 0 and a.mode == "bsdf" else ""),
-                       "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce_last_step_rank0": [int(c) for c in counts],
+                       "iterations_per_step": IPS, "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce_last_step_rank0": [int(c) for c in counts],
                        "sharding": "none" if N == 1 else (f"interleaved row tiles of {a.tile_rows} rows (tile % {N} == rank), {spp} sample(s) of the owned "
                                                           f"pixels per launch, one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
                        "pipeline": "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync"},
-            "device_ms_per_step": round(dev_ms / a.steps, 4),
+            "device_ms_per_step": round(dev_ms / a.steps, 4), "ms_per_iteration": round(1e3 * elapsed / (a.steps * IPS), 4),
             "overlap_note": (f"{a.in_flight} iterations in flight on {a.in_flight} streams: ms_per_step is smaller than the sum of the "
                              "per-kernel times of one iteration (roofline.note) because iterations overlap") if a.in_flight > 1 else None,
             "reference_order": ref_order,
@@ -377,7 +383,7 @@ def main():
             out["multi_gpu"] = multi
         if N == 1:
             # how busy the vector ALUs are over the TIMED region: VALU-active cycles of every kernel of one iteration (committed
-            # single-stream PMC pass, SQ_ACTIVE_INST_VALU in quad-cycles) / (1024 SIMDs x wall cycles of one step at the 2.39 GHz
+            # single-stream PMC pass, SQ_ACTIVE_INST_VALU in quad-cycles) / (1024 SIMDs x wall cycles of one iteration at the 2.39 GHz
             # rocm-smi shows during this run).  With iterations in flight the kernels overlap; their instruction counts do not change.
             rec = pmc_record(a.scene) if (scene.width, scene.height) == (800, 800) and res is None and a.depth < 0 else None
             if rec:
@@ -387,7 +393,7 @@ def main():
                     if c and "SQ_ACTIVE_INST_VALU" in c and k != "counters":
                         per_iter += c["SQ_ACTIVE_INST_VALU"] * (1 if k == "k_generate" else scene.trace_depth)
                 cyc = 4.0 * per_iter / 1024.0
-                out["valu_busy_estimate"] = {"frac": round(cyc / (1e-3 * out["ms_per_step"] * 2.39e9), 3), "valu_active_cycles_per_simd_per_step": round(cyc),
+                out["valu_busy_estimate"] = {"frac": round(cyc / (1e-3 * out["ms_per_iteration"] * 2.39e9), 3), "valu_active_cycles_per_simd_per_iteration": round(cyc),
                                              "clock_GHz_assumed": 2.39, "source": PMC_FILE,
                                              "note": "the timed configuration is bound by vector-ALU issue, not by HBM: see roofline.counters and DESIGN.md section 5"}
         out.update(extra)
