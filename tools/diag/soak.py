@@ -1,0 +1,22 @@
+"""GPU soak: long renders with iterations in flight + graph replay (and the sparse tail) twice; the two images must be
+bit-identical (determinism), finite and non-negative."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
+for scn, mode, iters, kw in (("cornell.txt", 0, 3000, dict(in_flight=3, graph=True)), ("mis_test.txt", 2, 3000, dict(in_flight=3, graph=True)),
+                             ("bunny_cornell.txt", 2, 600, dict(in_flight=3, graph=True)), ("bunny_cornell.txt", 0, 300, dict(in_flight=1))):
+    imgs = []
+    for rep in range(2):
+        s = ptk.Scene(os.path.join(ROOT, "scenes", scn))
+        r = ptk.Renderer(s, mode, **kw)
+        t0 = time.time()
+        for it in range(1, iters + 1): r.iterate(it)
+        img = r.image(); dt = time.time() - t0
+        rays = r.ray_total()
+        r.close(); s.close()
+        imgs.append(img)
+    ok = np.array_equal(imgs[0], imgs[1]) and np.isfinite(imgs[0]).all() and (imgs[0] >= 0).all()
+    print(f"{scn} mode {mode} {iters} iterations {kw}: {'deterministic' if ok else 'MISMATCH'}, {rays / dt / 1e9:.2f} Grays/s incl. readback, mean radiance {imgs[0].mean() / iters:.5f}")
+    assert ok
