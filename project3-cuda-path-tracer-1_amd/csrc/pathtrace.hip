@@ -180,6 +180,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.ray_total = g.ray_total;
     l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline < 4);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
+    l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4;          // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
     l.ws.fused = (g.pipeline == 3);
     l.ws.segmented = (g.pipeline != 4);
     l.ws.capacity = g.capacity;
@@ -499,7 +500,7 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 9) return PTK_E_BADARG;
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which < 4); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which < 4); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     return 0;

@@ -67,6 +67,7 @@ struct Workspace {               // per-render-context scratch, device memory
                                  // a separate k_segments launch does the bookkeeping (pipeline 7, A/B)
     bool segmented = true;       // false: k_scatter moves the survivors (pipeline 4)
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
+    int wide_lpr = 4;            // lanes per ray of the wide walk (4 or 2; ptk_kernels.hip k_traverse_wide)
     int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)
     int capacity = 0;
 };

@@ -405,7 +405,10 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
 // only leaf visits have effects, inner tests only prune, so any conservative pruning + the reference's leaf order gives
 // bit-identical winners).
 //
-// FOUR LANES PER RAY (a "quad"; 16 rays per wave64, 64 per block).  The work list of a bounce holds ~150 k rays on a
+// SEVERAL LANES PER RAY (template LPR: 4 = a "quad", 16 rays per wave64, described below; 2 = a pair, each lane owns four
+// children — fewer instructions per ray (frame, ballots, pushes and leaf code are shared by twice the rays), longer chain.
+// Measured on the bunny scene, Grays/s at 1 / 3 iterations in flight: LPR 1: 2.56 / 5.40, 2: 3.08 / 5.76, 4: 3.29 / 5.51, 8: 3.08 /
+// 4.63 — all bit-identical; the render loop uses 4 with one iteration at a time and 2 when several keep the machine full).  The work list of a bounce holds ~150 k rays on a
 // machine with 524 k lane slots: with one ray per lane the walk runs at ~2 waves per SIMD and its time is the dependent
 // chain of the slowest lane (measured: one-lane-per-ray over this same tree 185 us per launch, the threaded walk 125 us).
 // A quad shortens the chain and quadruples the waves: lane q of a quad owns children q and q + 4 of the node, so a visit is
@@ -431,7 +434,6 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
 #endif
 #define PTK_WIDE_STACK 24         // stack entries per ray
 #define PTK_WIDE_STRIDE 25        // odd: the 16 rays of a wave spread over the LDS banks
-#define PTK_WIDE_RAYS (PTK_BLOCK / 4)
 #define PTK_WIDE_LEAF 0x80000000u
 
 struct WideRay { f3 o, d, inv; float t_min; int tri; float u, v; int dir; };
@@ -469,20 +471,21 @@ __device__ __forceinline__ int wide_leaf_visit(const uint4 l0, const uint4 l1, c
     return 1;
 }
 
-template <bool STATS>
+template <bool STATS, int LPR>       // LPR lanes per ray (4: shortest chain; 2: fewer instructions per ray, see the header comment)
 __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
                                                               const int* __restrict__ srcidx) {
+    constexpr int RAYS = PTK_BLOCK / LPR, NCH = 8 / LPR;          // rays per block; children per lane
     __shared__ uint4 s_top[PTK_WIDE_TOP * 9];
-    __shared__ unsigned s_stack[PTK_WIDE_RAYS * PTK_WIDE_STRIDE];
+    __shared__ unsigned s_stack[RAYS * PTK_WIDE_STRIDE];
     const int m = (int)*list_count;
-    if (blockIdx.x * PTK_WIDE_RAYS >= m) return;
+    if (blockIdx.x * RAYS >= m) return;
     const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
     for (int k = threadIdx.x; k < n_top * 9; k += PTK_BLOCK) s_top[k] = S.wnodes[k];
     __syncthreads();
-    const int q = threadIdx.x & 3;                               // lane within the quad
-    const int qsh = (threadIdx.x & 63) & ~3;                     // first lane of the quad within the wave
-    const int j = blockIdx.x * PTK_WIDE_RAYS + (threadIdx.x >> 2);
+    const int q = threadIdx.x & (LPR - 1);                       // lane within the ray's group
+    const int qsh = (threadIdx.x & 63) & ~(LPR - 1);             // first lane of the group within the wave
+    const int j = blockIdx.x * RAYS + threadIdx.x / LPR;
     unsigned nv = 0, nt = 0;
     if (j < m) {
         const int ray = list[j];
@@ -498,16 +501,25 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
         // the fast slab test needs finite non-zero 1/d (Bounds3.hpp:174-177 otherwise); |d_k| >= 1e-30 keeps 2^e / d finite
         bool threaded = !(fabsf(r.d.x) >= 1e-30f && fabsf(r.d.y) >= 1e-30f && fabsf(r.d.z) >= 1e-30f);
         if (!threaded) {
-            unsigned* stk = s_stack + (threadIdx.x >> 2) * PTK_WIDE_STRIDE;
+            unsigned* stk = s_stack + (threadIdx.x / LPR) * PTK_WIDE_STRIDE;
             WideFrame f;
             f.px = r.inv.x > 0.f; f.py = r.inv.y > 0.f; f.pz = r.inv.z > 0.f;
             int sp = 0;
             unsigned cur = 0u;                                   // root
             for (;;) {
                 if (!(cur & PTK_WIDE_LEAF)) {
-                    uint4 q0, ca, cb;
-                    if ((int)cur < n_top) { const uint4* np = s_top + cur * 9; q0 = np[0]; ca = np[1 + q]; cb = np[5 + q]; asm volatile("" : "+v"(q0.x), "+v"(ca.x), "+v"(cb.x)); }
-                    else { const uint4* np = S.wnodes + (size_t)cur * 9; q0 = np[0]; ca = np[1 + q]; cb = np[5 + q]; asm volatile("" : "+v"(q0.x), "+v"(ca.x), "+v"(cb.x)); }
+                    uint4 q0, ch[NCH];                           // lane q owns children q, q + LPR, ...
+                    if ((int)cur < n_top) {
+                        const uint4* np = s_top + cur * 9; q0 = np[0];
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
+                        asm volatile("" : "+v"(q0.x), "+v"(ch[0].x));
+                    } else {
+                        const uint4* np = S.wnodes + (size_t)cur * 9; q0 = np[0];
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
+                        asm volatile("" : "+v"(q0.x), "+v"(ch[0].x));
+                    }
                     if (STATS) nv += (q == 0);
                     const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
                     f.Ax = sx * r.inv.x; f.Ay = sy * r.inv.y; f.Az = sz * r.inv.z;                     // exact (power-of-two scale)
@@ -516,15 +528,20 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
                     const float mx = K * (fabsf(Bx) + 255.f * fabsf(f.Ax)) + 1e-36f, my = K * (fabsf(By) + 255.f * fabsf(f.Ay)) + 1e-36f, mz = K * (fabsf(Bz) + 255.f * fabsf(f.Az)) + 1e-36f;
                     f.Bnx = Bx - mx; f.Bfx = Bx + mx; f.Bny = By - my; f.Bfy = By + my; f.Bnz = Bz - mz; f.Bfz = Bz + mz;
                     const int nc = (int)(q0.w >> 24);
-                    const bool ha = (q < nc) & wide_child_test(ca, f, r.t_min);       // no short circuit: straight-line code
-                    const bool hb = (q + 4 < nc) & wide_child_test(cb, f, r.t_min);
-                    const unsigned long long b0 = __ballot(ha), b1 = __ballot(hb);
-                    const unsigned H = ((unsigned)(b0 >> qsh) & 15u) | (((unsigned)(b1 >> qsh) & 15u) << 4);    // hit children of this ray
+                    bool hit[NCH];
+                    unsigned H = 0u;                              // hit children of this ray (bit = child index)
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        hit[k] = (q + LPR * k < nc) & wide_child_test(ch[k], f, r.t_min);      // no short circuit: straight-line code
+                        const unsigned long long bal = __ballot(hit[k]);
+                        H |= ((unsigned)(bal >> qsh) & ((1u << LPR) - 1u)) << (LPR * k);
+                    }
                     const int nh = __popc(H);
                     if (sp + nh > PTK_WIDE_STACK) { threaded = true; break; }
                     // all hit children at once, in reverse visiting order: the child visited first ends on top
-                    if (ha) stk[sp + nh - 1 - __popc(H & wide_before(ca, r.dir))] = ca.w;
-                    if (hb) stk[sp + nh - 1 - __popc(H & wide_before(cb, r.dir))] = cb.w;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k)
+                        if (hit[k]) stk[sp + nh - 1 - __popc(H & wide_before(ch[k], r.dir))] = ch[k].w;
                     sp += nh;
                 } else {
                     const uint4* lp = S.wleaves + (size_t)(cur & ~PTK_WIDE_LEAF) * 4;
@@ -1429,7 +1446,7 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
-                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED) {
+                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED, int wide_lpr = 4) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
@@ -1447,8 +1464,9 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
-    if (wide && stats && wide_stats) k_traverse_wide<true><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
-    else if (wide && !stats) k_traverse_wide<false><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
@@ -1475,7 +1493,7 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
     if (seg && depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
     // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
-                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk);
+                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr);
     if (rc) return rc;
     if (S.env_tex >= 0) {
         k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride, G.src);
