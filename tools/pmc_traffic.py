@@ -12,7 +12,7 @@ import re
 import sys
 
 KERNELS = (("k_intersect<false, false>", "k_intersect"), ("k_intersect<false, true>", "k_intersect_split"), ("k_list", "k_list"),
-           ("k_traverse_wide<false>", "k_traverse_wide"), ("k_traverse<false>", "k_traverse"), ("k_finalize", "k_finalize"),
+           ("k_traverse_wide<false, 4>", "k_traverse_wide"), ("k_traverse<false>", "k_traverse"), ("k_finalize", "k_finalize"),
            ("k_shade_binned", "k_shade_binned"), ("k_generate", "k_generate"))
 
 
