@@ -1392,6 +1392,8 @@ int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, in
 unsigned* g_abi_queue = nullptr;       // traversal list counter + list for the kernel-level ptk_intersect entry point
 int* g_abi_list = nullptr;
 int g_abi_list_cap = 0;
+int* g_abi_hflag = nullptr;             // work-list flags / per-block counts of the same entry point (same layout as the render loop)
+int* g_abi_hagg = nullptr;
 int g_fused_block = 256;               // threads per block of k_bounce (256 or 512)
 
 template <int MODE, int NT>
@@ -1600,14 +1602,18 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
         e = hipMemset(g_abi_queue, 0, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
     }
     if (n > g_abi_list_cap) {
-        if (g_abi_list) (void)hipFree(g_abi_list);
-        g_abi_list = nullptr; g_abi_list_cap = 0;
+        for (int** p : {&g_abi_list, &g_abi_hflag, &g_abi_hagg}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        g_abi_list_cap = 0;
         hipError_t e = hipMalloc(&g_abi_list, sizeof(int) * (size_t)n); if (e != hipSuccess) return (int)e;
+        if ((e = hipMalloc(&g_abi_hflag, sizeof(int) * (size_t)n)) != hipSuccess) return (int)e;
+        if ((e = hipMalloc(&g_abi_hagg, sizeof(int) * (size_t)(grid_for(n) + 1))) != hipSuccess) return (int)e;
         g_abi_list_cap = n;
     }
     const SceneView S = dev_view(*s->scene);
+    // the render loop's own layout: analytic primitives + root-box test, work list, BVH walk (the 8-wide collapsed tree; with `stats`
+    // the reference's threaded walk, whose visits the counters describe), finalize
     int rc = launch_intersect_stage(S, n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
-                                    nullptr, nullptr, true, (hipStream_t)stream, [](int, bool) {}, Gather{nullptr, nullptr, nullptr});
+                                    g_abi_hflag, g_abi_hagg, false, (hipStream_t)stream, [](int, bool) {}, Gather{nullptr, nullptr, nullptr}, PTK_WALK_WIDE, 4);
     if (rc || !img || S.env_tex < 0) return rc;
     if (!paths.col_pdf) return PTK_E_BADARG;
     k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, img, 0u, nullptr);

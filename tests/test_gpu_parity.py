@@ -729,3 +729,46 @@ def test_degenerate_scenes(ptk, orc, torch_cuda, tmp_path):
                     assert np.array_equal(r.live_counts()[0], lives[k]), (name, mode, pipeline, it)
                 img = r.image(); r.close()
                 assert np.array_equal(img, ref), (name, mode, pipeline)
+
+
+def test_wide_walk_stack_overflow_falls_back(ptk, orc, torch_cuda, tmp_path):
+    """A mesh built to overflow the wide walk's per-ray stack (24 entries): 4 096 triangles stacked along the view direction, so a
+    camera ray enters all eight children of every wide node on its way down (7 pushes per level, four levels) before it reaches its
+    first leaf.  Those rays take the threaded walk instead (k_traverse_wide's fallback); hit records through ptk_intersect and the
+    rendered image == oracle, and the host-side stack bound says why."""
+    torch = torch_cuda
+    N = 4096
+    with open(tmp_path / "stack.obj", "w") as f:
+        for i in range(N):
+            z = -0.002 * i
+            f.write(f"v -1 -1 {z}\nv 1 -1 {z}\nv 0 1 {z}\n")
+        for i in range(N):
+            f.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+    scene = ("MATERIAL l\nTYPE Light\nALBEDO 4 4 4\n\nMATERIAL d\nTYPE Lambertian\nALBEDO .7 .6 .5\n\n"
+             "CAMERA\nRES 48 48\nFOVY 12\nITERATIONS 2\nDEPTH 3\nFILE x\nEYE 0 0 6\nLOOKAT 0 0 0\nUP 0 1 0\n\n"
+             "OBJECT light\nsphere\nmaterial l\nTRANS 0 3 4\nROTAT 0 0 0\nSCALE 2 2 2\n\n"
+             "OBJECT mesh\nstack.obj\nmaterial d\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n")
+    p = tmp_path / "stack.txt"; p.write_text(scene)
+    s = ptk.Scene(str(p)); o = orc.Scene(str(p))
+    assert s.n_triangles == N
+    _, _, depth, bound = s.wide_bvh()
+    assert depth >= 4 and bound > 24                      # deeper than the kernel's stack: the fallback is what is being tested
+    # first-bounce hit records of every camera ray (kernel-level entry point = the render loop's layout, wide walk included)
+    paths = o.generate_rays(1)
+    ref_is, ref_valid = o.intersect(paths)
+    A = _to_dev(torch, orc.paths_to_soa(paths)); H = ptk.new_paths(len(paths))
+    valid = torch.zeros(len(paths), dtype=torch.int32, device="cuda")
+    ptk.intersect(s.upload(), len(paths), A, H, valid)
+    assert np.array_equal(valid.cpu().numpy(), ref_valid)
+    m = ref_valid.astype(bool)
+    assert (ref_is["triangleID"][m] >= 0).sum() > 100     # most camera rays hit the stack of triangles
+    _eq_fields(orc.isects_from_soa(*[h.cpu().numpy() for h in H])[m], ref_is[m], what="stack")
+    for mode in (0, 2):
+        ref = np.zeros((o.P, 3), np.float32)
+        lives = [o.pathtrace(mode, it, ref)[1] for it in (1, 2)]
+        r = ptk.Renderer(s, mode)
+        for k, it in enumerate((1, 2)):
+            r.iterate(it)
+            assert np.array_equal(r.live_counts()[0], lives[k]), (mode, it)
+        img = r.image(); r.close()
+        assert np.array_equal(img, ref), mode
