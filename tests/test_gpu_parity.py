@@ -772,3 +772,23 @@ def test_wide_walk_stack_overflow_falls_back(ptk, orc, torch_cuda, tmp_path):
             assert np.array_equal(r.live_counts()[0], lives[k]), (mode, it)
         img = r.image(); r.close()
         assert np.array_equal(img, ref), mode
+
+
+@pytest.mark.parametrize("mode", ["BSDF", "MIS"])
+def test_sparse_tail_textured(ptk, orc, torch_cuda, tmp_path, mode):
+    """k_tail with everything the in-lane intersect / shading code can meet: uv-mapped mesh with albedo / roughness / metallic /
+    normal maps, ENV radiance on misses, shadow rays — a 64x48 frame puts all but the first bounce in the tail after a few
+    iterations.  Twelve iterations == oracle."""
+    import texture_scene
+    path = texture_scene.make(tmp_path, res=(64, 48), depth=6, env=True)
+    m = MODES[mode]
+    s = ptk.Scene(path); o = orc.Scene(path)
+    r = ptk.Renderer(s, m)
+    ref = np.zeros((o.P, 3), np.float32)
+    for it in range(1, 13):
+        r.iterate(it)
+        _, live = o.pathtrace(m, it, ref)
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (it, counts, live)
+    img = r.image(); r.close()
+    assert ref.sum() > 0 and np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
