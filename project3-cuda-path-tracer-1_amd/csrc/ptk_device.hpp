@@ -269,11 +269,12 @@ PTK_DI f3 xform_nrm_d(const float* m, f3 v, int diag) {
 
 // ---- primitives -----------------------------------------------------------------------------------
 // The part of a primitive record the exact tests read (inverseTransform, transform, diag), as a per-lane register copy.
-// Staged form: kernels copy dwords [2, 26) of every DevGeom into LDS once per block (stage_geoms), 24 floats = 96 B per
-// primitive, and each lane fetches the record of ITS current candidate with six ds_read_b128.
+// Staged form: kernels copy every DevGeom into LDS once per block (stage_geoms) as {inv[12], fwd[12], invT[9], diag, materialid,
+// pad} = 36 floats = 144 B per primitive; each lane fetches the matrices of ITS current candidate with ds_read_b128, and the hit
+// record reads invT / materialid from the same copy (analytic_record_staged).
 struct GeomXf { float inv[12], fwd[12]; int diag; };
 #define PTK_XF_FLOATS 36            // staged record: inv[12], fwd[12], invT[9], diag, materialid, pad (ptk_kernels.hip: stage_geoms)
-#define PTK_LDS_GEOMS_MAX 512          // 48 KB of LDS; larger scenes use the wave-uniform loops
+#define PTK_LDS_GEOMS_MAX 512          // 72 KB of LDS; larger scenes use the wave-uniform loops
 struct GeomStage { const float* xf; bool on; };
 // the same record by reference: the exact tests read inv / fwd from LDS where they use them (fwd only on a hit), which keeps
 // 12-24 registers free compared with the by-value copy
