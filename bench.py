@@ -60,7 +60,10 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--in-flight", type=int, default=3, help="iterations in flight (ptk_set_iterations_in_flight)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay iterations from a hipGraph")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: samples per launch = N (weak) or 1 (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: per-GPU work fixed (weak) or whole-job work fixed (strong)")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
+                    help="N > 1: what the headline run shards — interleaved row tiles of the frame (north star) or whole-frame iterations "
+                         "(rank g renders iterations g+1, g+1+N, ...: the exact validation mode of SURVEY 8e); the other one is reported in multi_gpu")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--bvh-scene", default="bunny_cornell.txt", help="second roofline measurement on a BVH scene ('' = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="ptk_set_pipeline value (A/B comparisons)")
@@ -219,8 +222,23 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
     }
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks ourselves, BEFORE torch is imported or the GPU is touched in
+    this process (the parent never initialises HIP), relay their output (rank 0 prints the JSON line) and return their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
@@ -228,11 +246,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    N = a.gpus
-    if world != N:
-        if world == 1 and N > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        N = world
+    N = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
@@ -244,87 +258,104 @@ def main():
     scene_path = os.path.join(ROOT, "scenes", a.scene)
     res = tuple(a.res) if a.res else None
     scene = ptk.Scene(scene_path, res=res, depth=a.depth)
-    # N > 1: rank r owns the row tiles t with t % N == r and traces N samples of them per launch ("weak": every rank launches
-    # W*H paths per step, exactly like the single GPU); "strong": one sample per launch (per-rank launches shrink by N).
-    weak = N > 1 and a.scaling == "weak"
-    spp = N if weak else 1
-    part = (N, rank, a.tile_rows) if N > 1 else (1, 0, 1)
-    r = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), spp=spp)
     P = scene.width * scene.height
     red = torch.zeros((P, 3), dtype=torch.float32, device="cuda") if N > 1 else None
-
-    def barrier():
-        r.sync(); torch.cuda.synchronize()
-        if N > 1:
-            dist.barrier()
-
-    def reduce_radiance():
-        """the job's one collective: SUM-reduce of the full-frame float32 radiance buffer to rank 0"""
-        r.image_to(red)
-        if a.backend == "nccl":
-            dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
-        else:                                  # rehearsal backends: stage through the host
-            h = red.cpu(); dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-
-    it = 0
     IPS = max(1, a.iters_per_step)
-    for _ in range(a.warmup * IPS):
-        it += 1; r.iterate(it)
-    if N > 1:                      # warm the communicator outside the timed region
-        reduce_radiance()
-    barrier()
-    rays0 = r.ray_total()
-    barrier()
-    t0 = time.perf_counter()
-    r.timer_start()
-    for _ in range(a.steps * IPS):
-        it += 1; r.iterate(it)
-    dev_ms = r.timer_stop()
-    if N > 1:
-        reduce_radiance()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    rays = r.ray_total() - rays0
-    counts, traced = r.live_counts()
-    r.close()
-    if N > 1:
-        dev = "cuda" if a.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
-        q = torch.tensor([rays], dtype=torch.int64, device=dev); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
+    cdev = "cuda" if a.backend == "nccl" else "cpu"
+
+    def run_job(shard, scaling):
+        """One timed job of K steps.  shard "tiles": rank r owns the row tiles t % N == r and traces N (weak) or 1 (strong) samples
+        of them per launch.  shard "iterations": rank r renders iterations r+1, r+1+N, ... of the whole frame — K*IPS calls per rank
+        (weak: the job renders N*K*IPS iterations) or K*IPS/N calls per rank (strong: the job renders K*IPS iterations).
+        Timed region: barrier + synchronize, the calls (no host synchronisation inside), ONE reduce(SUM) of the float32[3*W*H]
+        radiance buffer to rank 0, synchronize + barrier; returns rays of all ranks, MAX over ranks of the time, and this rank's
+        renderer-side figures."""
+        weak = scaling == "weak"
+        if N == 1:
+            r = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph))
+            calls, spp = a.steps * IPS, 1
+        elif shard == "tiles":
+            spp = N if weak else 1
+            r = ptk.Renderer(scene, mode, partition=(N, rank, a.tile_rows), pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), spp=spp)
+            calls = a.steps * IPS
+        else:
+            spp = 1
+            r = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), shard=(N, rank))
+            calls = a.steps * IPS if weak else max(1, (a.steps * IPS + N - 1) // N)
+
+        def barrier():
+            r.sync(); torch.cuda.synchronize()
+            if N > 1:
+                dist.barrier()
+
+        def reduce_radiance():
+            """the job's one collective: SUM-reduce of the full-frame float32 radiance buffer to rank 0"""
+            r.image_to(red)
+            if a.backend == "nccl":
+                dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
+            else:                                  # rehearsal backends: stage through the host
+                h = red.cpu(); dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+
+        it = 0
+        for _ in range(a.warmup * IPS):
+            it += 1; r.iterate(it)
+        if N > 1:                      # warm the communicator outside the timed region
+            reduce_radiance()
+        barrier()
+        rays0 = r.ray_total()
+        barrier()
+        t0 = time.perf_counter()
+        r.timer_start()
+        for _ in range(calls):
+            it += 1; r.iterate(it)
+        dev_ms = r.timer_stop()
+        if N > 1:
+            reduce_radiance()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        rays = r.ray_total() - rays0
+        counts, _ = r.live_counts()
+        t_red = 0.0
+        if N > 1:
+            t_red0 = time.perf_counter()
+            for _ in range(5):
+                reduce_radiance()
+            barrier()
+            t_red = (time.perf_counter() - t_red0) / 5
+        r.close()
+        if N > 1:
+            t = torch.tensor([elapsed, t_red], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, t_red = float(t[0].item()), float(t[1].item())
+            q = torch.tensor([rays], dtype=torch.int64, device=cdev); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
+        return {"rays": rays, "elapsed": elapsed, "dev_ms": dev_ms, "counts": counts, "spp": spp, "calls": calls, "reduce_s": t_red}
+
+    head = run_job(a.shard, a.scaling)
+    rays, elapsed, dev_ms, counts, spp = head["rays"], head["elapsed"], head["dev_ms"], head["counts"], head["spp"]
+    weak = N > 1 and a.scaling == "weak"
 
     multi = None
     if N > 1:
-        # the other scaling mode and the collective alone, measured after the headline (every rank takes part)
-        other_spp = 1 if weak else N
-        r2 = ptk.Renderer(scene, mode, partition=part, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), spp=other_spp)
-        r_saved, r = r, r2
-        for i in range(1, a.warmup * IPS + 1):
-            r.iterate(i)
-        barrier(); q0 = r.ray_total(); barrier()
-        tt0 = time.perf_counter()
-        for i in range(a.warmup * IPS + 1, (a.warmup + a.steps) * IPS + 1):
-            r.iterate(i)
-        reduce_radiance()
-        barrier()
-        tt = time.perf_counter() - tt0
-        q = r.ray_total() - q0
-        t_red0 = time.perf_counter()
-        for _ in range(5):
-            reduce_radiance()
-        barrier()
-        t_red = (time.perf_counter() - t_red0) / 5
-        r.close(); r = r_saved
-        dev = "cuda" if a.backend == "nccl" else "cpu"
-        t = torch.tensor([tt, t_red], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        qq = torch.tensor([q], dtype=torch.int64, device=dev); dist.all_reduce(qq, op=dist.ReduceOp.SUM)
-        this = {"value": round(rays / elapsed / 1e6, 3), "samples_per_launch": spp}
-        that = {"value": round(int(qq.item()) / float(t[0].item()) / 1e6, 3), "samples_per_launch": other_spp}
-        multi = {"weak": this if weak else that, "strong": that if weak else this, "unit": "Mrays/s",
-                 "reduce_ms": round(1e3 * float(t[1].item()), 4),
+        # the other three (shard, scaling) combinations and the collective alone, measured after the headline (every rank takes part)
+        def line(j):
+            return {"value": round(j["rays"] / j["elapsed"] / 1e6, 3), "samples_per_launch": j["spp"], "calls_per_rank": j["calls"],
+                    "ms": round(1e3 * j["elapsed"], 3)}
+        jobs = {(a.shard, a.scaling): head}
+        for sh in ("tiles", "iterations"):
+            for sc in ("weak", "strong"):
+                if (sh, sc) not in jobs:
+                    jobs[(sh, sc)] = run_job(sh, sc)
+        multi = {"weak": line(jobs[("tiles", "weak")]), "strong": line(jobs[("tiles", "strong")]),
+                 "iteration_sharded": {"weak": line(jobs[("iterations", "weak")]), "strong": line(jobs[("iterations", "strong")]),
+                                       "note": "rank g renders iterations g+1, g+1+N, ... of the WHOLE frame with the reference's own RNG keys "
+                                               "(ptk_set_iteration_sharding): every launch keeps the single-GPU width; the reduced image is the "
+                                               "single-GPU image with N iterations in flight up to the order of the float additions in the reduce"},
+                 "unit": "Mrays/s", "headline": f"{a.shard}/{a.scaling}",
+                 "reduce_ms": round(1e3 * head["reduce_s"], 4),
                  "reduce_note": "one dist.reduce(SUM) of the float32[3*W*H] radiance buffer to rank 0 (+ the device copy into the "
-                                "send buffer), mean of 5, max over ranks; it is inside both timed regions once",
-                 "note": "weak: every rank traces N samples of its tiles per launch (per-GPU work fixed); strong: one sample per "
-                         "launch (whole-frame work fixed, per-rank launches shrink by N)"}
+                                "send buffer), mean of 5, max over ranks; it is inside every timed region once",
+                 "note": "tiles (weak / strong): every rank traces N / 1 samples of its interleaved row tiles per launch (per-GPU work fixed / "
+                         "whole-frame work fixed, per-rank launches shrink by N); iteration_sharded (weak / strong): K*IPS / K*IPS/N "
+                         "whole-frame iterations per rank"}
     if rank == 0:
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
         roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)
@@ -369,8 +400,10 @@ def main():
             "config": {"workload": f"scenes/{a.scene} {scene.width}x{scene.height} depth {scene.trace_depth}, SampleMode {a.mode.upper()}"
                                    + (" (BASELINE configs[1])" if a.scene == "cornell.txt" and res is None and a.depth < 0 and a.mode == "bsdf" else ""),
                        "iterations_per_step": IPS, "rays_per_step": rays // max(a.steps, 1), "live_paths_per_bounce_last_step_rank0": [int(c) for c in counts],
-                       "sharding": "none" if N == 1 else (f"interleaved row tiles of {a.tile_rows} rows (tile % {N} == rank), {spp} sample(s) of the owned "
-                                                          f"pixels per launch, one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
+                       "sharding": "none" if N == 1 else ((f"interleaved row tiles of {a.tile_rows} rows (tile % {N} == rank), {spp} sample(s) of the owned pixels per launch"
+                                                           if a.shard == "tiles" else f"whole-frame iterations, rank g renders iterations g+1, g+1+{N}, ...")
+                                                          + ", one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
+                       "iterations_total": head["calls"] * (N if a.shard == "iterations" else 1) * spp,
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
                        "pipeline": "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync"},
             "device_ms_per_step": round(dev_ms / a.steps, 4), "ms_per_iteration": round(1e3 * elapsed / (a.steps * IPS), 4),

@@ -199,6 +199,18 @@ int ptk_get_ray_total(unsigned long long* rays);
 /* Restrict rendering to the pixels of interleaved tiles: pixel (x,y) is traced iff
  * ((y / tile_rows) % n_parts) == part.  (1,0,*) = whole frame.  Multi-GPU sharding, SURVEY §8e. */
 int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
+/* Iteration sharding — the exact multi-GPU validation mode of SURVEY §8e (set before ptk_pathtrace_init; (1,0) = off).
+ * ptk_pathtrace(.., step) then renders iteration (step-1)*n_shards + shard + 1 of the WHOLE frame, with the reference's own
+ * RNG keys (camera: (x, y, iter), pathtrace.cu:148 — shading: (iter, compacted slot, depth), pathtrace.cu:458,532), so shard g
+ * of n computes exactly the iterations g+1, g+1+n, ... of a single-GPU render: its radiance buffer is plane g of a single
+ * process with n iterations in flight, and the sum of the shards in rank order is that process's image bit for bit. */
+int ptk_set_iteration_sharding(int n_shards, int shard);
+/* Bounces currently enqueued at full width (the remaining ones run in the single-workgroup tail kernel); diagnostic. */
+int ptk_get_full_width_bounces(int* out);
+/* Test-only: offset k added to the compacted slot in the shading RNG key (pathtrace.cu:363,458,532), and a reset of the radiance
+ * buffer.  tests/test_gallery.py renders the reference's gallery/Direct20.png with the slot offsets its GPU build ran with. */
+int ptk_debug_slot_shift(int k);
+int ptk_debug_clear_image(void);
 /* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);

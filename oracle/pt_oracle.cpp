@@ -1657,6 +1657,8 @@ int orc_compact(int n, const int* valid, void* paths, void* isects) {
 long long orc_pathtrace_batch(OrcScene* S, int mode, int step, int spp, int n_parts, int part, int tile_rows, float* img, int* live, double* timing) {
     const Camera& cam = S->cam;
     int W = cam.res[0], H = cam.res[1];
+    // the rank-unique key slot + part * W * H * spp is a 32-bit int on both sides: refuse what would wrap (the product returns PTK_E_BADARG)
+    if (n_parts > 1 && (long long)part * W * H * spp + ((long long)W * H * spp) / n_parts + (long long)W * tile_rows * spp > 2147483647LL) return -1;
     g_plane_stride = 3 * (size_t)W * H;
     std::vector<PathSegment> paths; paths.reserve((size_t)W * H * spp / n_parts + W * tile_rows);
     using clk = std::chrono::steady_clock;

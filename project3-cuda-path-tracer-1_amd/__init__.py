@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
     "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_fused_block", "ptk_set_light_fix",
+    "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_debug_slot_shift", "ptk_debug_clear_image",
 ]
 
 
@@ -136,6 +137,9 @@ def _load() -> C.CDLL:
     lib.ptk_set_shade_binning.argtypes = [ci]
     lib.ptk_set_fused_block.argtypes = [ci]
     lib.ptk_set_light_fix.argtypes = [ci]
+    lib.ptk_set_iteration_sharding.argtypes = [ci, ci]
+    lib.ptk_get_full_width_bounces.argtypes = [C.POINTER(ci)]
+    lib.ptk_debug_slot_shift.argtypes = [ci]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
     lib.ptk_profile_end.argtypes = [vp, vp]
     lib.ptk_enable_traversal_stats.argtypes = [ci]
@@ -291,9 +295,11 @@ class Renderer:
     """File-static render context of the library (one at a time, like the reference)."""
 
     def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1), pipeline: int = 0, in_flight: int = 1,
-                 graph: bool = False, spp: int = 1):
+                 graph: bool = False, spp: int = 1, shard=(1, 0)):
+        """shard = (n, g): iterate(step) renders iteration (step-1)*n + g + 1 of the whole frame (ptk_set_iteration_sharding)"""
         self.scene = scene
         lib.ptk_pathtrace_free()
+        _chk(lib.ptk_set_iteration_sharding(*shard), "ptk_set_iteration_sharding")
         _chk(lib.ptk_set_samples_per_launch(spp), "ptk_set_samples_per_launch")
         _chk(lib.ptk_set_graph_replay(1 if graph else 0), "ptk_set_graph_replay")
         _chk(lib.ptk_set_iterations_in_flight(in_flight), "ptk_set_iterations_in_flight")
@@ -325,6 +331,11 @@ class Renderer:
         d = C.c_int(0)
         _chk(lib.ptk_get_live_counts(c.ctypes.data, C.byref(d)), "ptk_get_live_counts")
         return c, d.value
+
+    def full_width_bounces(self) -> int:
+        d = C.c_int(0)
+        _chk(lib.ptk_get_full_width_bounces(C.byref(d)), "ptk_get_full_width_bounces")
+        return d.value
 
     def ray_total(self) -> int:
         r = C.c_ulonglong(0)
@@ -362,3 +373,4 @@ class Renderer:
         lib.ptk_set_iterations_in_flight(1)
         lib.ptk_set_graph_replay(0)
         lib.ptk_set_samples_per_launch(1)
+        lib.ptk_set_iteration_sharding(1, 0)

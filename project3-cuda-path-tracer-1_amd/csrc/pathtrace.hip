@@ -47,6 +47,7 @@ struct Lane {
     int graph_full = -1;                // full-width bounces the captured graph contains
     int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
     bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
+    int fresh_hint = 0;                 // iterations enqueued on this lane since the hint was reset (read-backs every iteration at first)
 };
 
 struct RenderContext {
@@ -64,10 +65,13 @@ struct RenderContext {
     bool use_graph = false;
     int last_lane = 0;
     int full_bounces = 0;               // bounces enqueued at full width; the rest of an iteration runs in k_tail (sparse_tail())
+    int hint_mode = -1;                 // sample mode the full_bounces hint was learnt under
+    int n_shards = 1, shard = 0;        // iteration sharding (ptk_set_iteration_sharding): call `step` renders iteration (step-1)*n_shards + shard + 1
     bool live = false;
 } g;
 
 int g_mode_override = -1;               // ptk_set_sample_mode; -1 = follow the `sampleMode` global
+int g_debug_slot_shift = 0;             // ptk_debug_slot_shift: test-only offset of the shading RNG key (tests/test_gallery.py)
 
 template <typename T> int dalloc(T** p, size_t count) {
     *p = nullptr;
@@ -141,7 +145,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.plane_stride = 3u * (unsigned)g.P;
     l.ws.spp = g.spp;
     // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
-    l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;
+    l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;          // fits an int: checked in context_init
     if ((rc = alloc_paths(l.bufA, g.capacity))) return rc;
     if ((rc = alloc_paths(l.bufB, g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
@@ -197,10 +201,13 @@ int context_init(Scene* scene) {
     g.P = cam.resolution.x * cam.resolution.y;
     g.traceDepth = scene->state.traceDepth;
     g.full_bounces = g.traceDepth;                  // until live counts of earlier iterations say otherwise (note_counts)
+    g.hint_mode = -1;
     if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
     g.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
     g.capacity = g.n_pix * g.spp;
     if (g.P >= (1 << 24)) return PTK_E_BADARG;            // pixelIndex carries the sample plane in bits 24..30
+    // the rank-unique RNG key is slot + part * P * spp as a 32-bit int; refuse partitions whose largest key would wrap
+    if (g.n_parts > 1 && (long long)g.part * g.P * g.spp + (long long)g.capacity > 2147483647LL) return PTK_E_BADARG;
     int rc;
     hipError_t e;
     if ((e = hipEventCreate(&g.ev0)) != hipSuccess) return (int)e;
@@ -248,7 +255,8 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     const SceneView S = dev_view(*g.scene);
     Workspace ws = L.ws;
     ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
-    ws.iter_stride = g.n_lanes;
+    ws.iter_stride = g.n_lanes * g.n_shards;
+    ws.slot_bias += g_debug_slot_shift;
     prof_mark(0, true);
     int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, g.n_parts, g.part, g.tile_rows, g.n_pix, g.spp, ws.counts, L.stream);
     prof_mark(0, false);
@@ -289,7 +297,7 @@ void note_counts(Lane& L) {
 int request_counts(Lane& L) {
     if (!sparse_tail() || L.counts_pending) return 0;
     // the counts of a static scene barely move: look every iteration at first, then at every 16th (each look is a ~5-us copy kernel on the stream)
-    if (L.last_iter > 8 * g.n_lanes && (L.last_iter / g.n_lanes) % 16 != 0) return 0;
+    if (++L.fresh_hint > 8 && L.fresh_hint % 16 != 0) return 0;
     hipError_t e = hipMemcpyAsync(L.h_counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventRecord(L.counts_ev, L.stream)) != hipSuccess) return (int)e;
@@ -302,6 +310,9 @@ int request_counts(Lane& L) {
 // returns 0, a launch error of the captured kernels (> 0 or PTK_E_*), or -1000 when the graph machinery itself failed
 int build_graph(Lane& L, int iter, int mode) {
     hipError_t e;
+    // a recapture happens a handful of times per render (mode switch, full_bounces hint): let the lane's queued replays of the
+    // old exec finish before it is destroyed (whether the runtime defers the destroy itself is not documented)
+    if (L.graph_exec && hipStreamSynchronize(L.stream) != hipSuccess) return -1000;
     if (L.graph_exec) { (void)hipGraphExecDestroy(L.graph_exec); L.graph_exec = nullptr; }
     if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; }
     if ((e = hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return -1000;
@@ -337,15 +348,18 @@ int replay_iteration(Lane& L, int iter, int mode) {
         if ((e = hipStreamSynchronize(L.stream)) != hipSuccess) return (int)e;     // &iter is a stack address
     }
     if ((e = hipGraphLaunch(L.graph_exec, L.stream)) != hipSuccess) return (int)e;
-    L.expected_iter = iter + g.n_lanes;
+    L.expected_iter = iter + g.n_lanes * g.n_shards;
     return 0;
 }
 
-int render_iteration(unsigned char* pbo, int iter) {
+int render_iteration(unsigned char* pbo, int step) {
     (void)pbo;
     if (!g.live) return PTK_E_NOSCENE;
-    if (iter < 1) return PTK_E_BADARG;
-    const int li = (iter - 1) % g.n_lanes;
+    if (step < 1 || (long long)(step - 1) * g.n_shards + g.shard + 1 > 2147483647LL) return PTK_E_BADARG;
+    // iteration sharding (multi-GPU validation mode): this process renders iterations shard+1, shard+1+n, ... of the
+    // whole frame; lanes are assigned by call number so that every lane is used whatever n_shards is
+    const int iter = (step - 1) * g.n_shards + g.shard + 1;
+    const int li = (step - 1) % g.n_lanes;
     Lane& L = g.lanes[li];
     g.last_lane = li;
     L.last_iter = iter;
@@ -356,6 +370,13 @@ int render_iteration(unsigned char* pbo, int iter) {
         L.wait_resolved = false;
     }
     const int mode = current_mode();
+    if (mode != g.hint_mode) {
+        // the full-width hint was learnt from another sample mode's live counts (DIRECT dies after one bounce, BSDF
+        // does not): start again from "every bounce at full width" and ignore read-backs that are still in flight
+        g.full_bounces = g.traceDepth;
+        for (Lane& l : g.lanes) { l.counts_pending = false; l.fresh_hint = 0; }
+        g.hint_mode = mode;
+    }
     note_counts(L);
     int rc;
     if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
@@ -406,6 +427,7 @@ int ptk_pathtrace(unsigned char* pbo, int frame, int iter) {
     if (rc || !pbo) return rc;
     if ((rc = resolve_image())) return rc;
     const Camera& cam = g.scene->state.camera;
+    // samples accumulated so far by THIS process (with iteration sharding a call is one sample, whatever its iteration number)
     return ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter * g.spp, pbo, g.lanes[0].stream);
 }
 
@@ -498,6 +520,33 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
     const int lr = j / W, x = j - lr * W;
     const int y = ((lr / tile_rows) * n_parts + part) * tile_rows + (lr % tile_rows);
     return x + y * W;
+}
+/* Iteration sharding (SURVEY 8e validation mode; set before ptk_pathtrace_init): ptk_pathtrace(.., step) renders iteration
+ * (step-1)*n_shards + shard + 1 of the WHOLE frame with the reference's own RNG keys (camera key (x, y, iter), pathtrace.cu:148;
+ * shading key (iter, compacted slot, depth), :458,532).  Shard g of n then holds exactly the radiance plane g of a single
+ * process running n iterations in flight; the sum of the shards in rank order is that process's image, bit for bit. */
+int ptk_set_iteration_sharding(int n_shards, int shard) {
+    if (n_shards < 1 || shard < 0 || shard >= n_shards || g.live) return PTK_E_BADARG;
+    g.n_shards = n_shards; g.shard = shard;
+    return 0;
+}
+/* Bounces the render loop currently enqueues at full width (the rest of an iteration runs in the single-workgroup k_tail);
+ * trace depth until live counts of earlier iterations have been seen.  Diagnostic. */
+int ptk_get_full_width_bounces(int* out) {
+    if (!g.live) return PTK_E_NOSCENE;
+    if (!out) return PTK_E_BADARG;
+    *out = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
+    return 0;
+}
+/* TEST-ONLY knobs (tests/test_gallery.py: the HIP path against the reference's own gallery pixels).  ptk_debug_slot_shift(k): the
+ * shading kernels key their RNG by compacted slot + k (the reference's GPU build flipped a few silhouette pixels per iteration, which
+ * shifts every later slot by a small constant; tests/golden/make_gallery_fixture.py).  ptk_debug_clear_image(): zero the radiance
+ * planes, so that single iterations can be read back one by one. */
+int ptk_debug_slot_shift(int k) { g_debug_slot_shift = k; invalidate_graphs(); return 0; }
+int ptk_debug_clear_image(void) {
+    if (!g.live) return PTK_E_NOSCENE;
+    sync_all();
+    return rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
 }
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 9) return PTK_E_BADARG;

@@ -180,7 +180,7 @@ struct SceneView {
     const DevMaterial* mats;     int n_mats;
     const DevNode* nodes;        int bvh_size;   // [6][bvh_size]
     const DevTriE* trie;         // traversal form of the triangles
-    const uint4* wnodes;         int n_wnodes;   // 8-wide collapsed form of the same tree (WideNode, 6 x uint4 each); null = none
+    const uint4* wnodes;         int n_wnodes;   // 8-wide collapsed form of the same tree (WideNode, 9 x uint4 = 144 B each); null = none
     const uint4* wleaves;        // WideLeaf records (4 x uint4 each), children of one wide node consecutive
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;

@@ -106,7 +106,7 @@ public:
     void* dev_materials = nullptr;    // ptk::DevMaterial[]
     void* dev_nodes = nullptr;        // ptk::DevNode[6][bvh_size]
     void* dev_trie = nullptr;         // ptk::DevTriE[]
-    void* dev_wnodes = nullptr;       // 8-wide collapsed tree (wide_bvh.h), 96 B per node; null if the tree could not be collapsed
+    void* dev_wnodes = nullptr;       // 8-wide collapsed tree (wide_bvh.h), 144 B = 9 x uint4 per node; null if the tree could not be collapsed
     void* dev_wleaves = nullptr;      // its leaf records, 64 B each
     int wide_nodes = 0, wide_depth = 0, wide_stack = 0;
     void* dev_triv = nullptr;         // ptk::DevTriV[]

@@ -98,7 +98,8 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
             const long double ext = hi - p;
             if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2((double)(ext / 255.0L))) - 1);
             while (p + 255.0L * std::ldexp(1.0L, e) < hi) ++e;
-            if (e > 60) return false;                                 // absurd extents: scale * (1 / d) could overflow on the device
+            if (e > 20) return false;                                 // the kernel admits |1 / d| up to 1e30: q * (2^e / d) with q <= 255 stays finite (no +inf near
+                                                                      // plane that would cull a child wrongly) only for e <= 20; larger extents (> 2.7e8 units) -> threaded walk
             eb[a] = (uint32_t)(e + 127);
             const long double s = std::ldexp(1.0L, e);
             for (int c = 0; c < 8; ++c) { qlo[a][c] = 255; qhi[a][c] = 0; }

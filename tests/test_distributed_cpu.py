@@ -100,3 +100,56 @@ def test_partition_ranks_use_distinct_random_streams(orc, scenes_dir):
     assert noise_corr(a, b_shared) > 0.1          # measured 0.17
     assert abs(noise_corr(a, b)) < 0.05           # measured -0.01
     s.close()
+
+
+def _iter_shard_worker(rank, world, port, steps, out_dir):
+    """two gloo ranks, each the CPU restatement of `ptk_set_iteration_sharding(world, rank)`: iterations rank+1, rank+1+world, ..."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as orc
+    orc.set_trig_mode(orc.TRIG_PTK)
+    s = orc.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(48, 40), depth=3)
+    img = np.zeros((s.P, 3), np.float32); rays = 0
+    for step in range(1, steps + 1):
+        r, _ = s.pathtrace(0, (step - 1) * world + rank + 1, img); rays += r
+    t = torch.from_numpy(img.copy())
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+    q = torch.tensor([rays], dtype=torch.int64); dist.all_reduce(q, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "img.npy"), t.numpy()); np.save(os.path.join(out_dir, "rays.npy"), q.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_iteration_sharding_is_the_single_process_render(tmp_path, orc, scenes_dir):
+    """SURVEY 8e validation mode, CPU tier: rank g of 2 renders iterations g+1, g+3, ... of the whole frame with the reference's own
+    keys; the SUM-reduced buffer equals (plane0 + plane1) of ONE process that renders iterations 1..2K with plane l = iterations
+    l+1, l+3, ... (what the product does with two iterations in flight), bit for bit, and the ray counts add up."""
+    world, steps = 2, 3
+    mp.spawn(_iter_shard_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    img = np.load(tmp_path / "img.npy"); rays = int(np.load(tmp_path / "rays.npy")[0])
+    orc.set_trig_mode(orc.TRIG_PTK)
+    s = orc.Scene(os.path.join(scenes_dir, "cornell.txt"), res=(48, 40), depth=3)
+    planes = np.zeros((world, s.P, 3), np.float32); ref = 0
+    for it in range(1, world * steps + 1):
+        r, _ = s.pathtrace(0, it, planes[(it - 1) % world]); ref += r
+    assert rays == ref
+    assert np.array_equal(img, planes[0] + planes[1])
+    assert img.sum() > 0
+    s.close()
+
+
+def test_bench_self_launch_starts_ranks_without_gpu(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell starts the ranks itself (no WORLD_SIZE needed).  Without a GPU every rank stops
+    at 'needs a GPU' — the point here is that the launcher ran both ranks and handed their exit code on (the rc-0 run with its JSON
+    line is the -m gpu test tests/test_gpu_multirank.py::test_bench_self_launches_two_ranks)."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-tier test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    assert "launch with: python -m torch.distributed.run" not in r.stderr

@@ -201,3 +201,37 @@ def test_gpu_gallery_2000spp(ptk, name):
     # measured: Direct 0.993 / 0.23 levels; BSDF sampling alone rarely finds the small lights, its 2000-spp image is still
     # noisy (the gallery's own too): 0.45 / 2.96 levels
     assert frac2 > (0.35 if name == "BSDF" else 0.97) and d[lit].mean() < (4.5 if name == "BSDF" else 0.6), frac2
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_gallery_pixels_direct20(ptk):
+    """the HIP path against the reference's own pixels DIRECTLY (not through the oracle).  gallery/Direct20.png,
+    iteration by iteration, with the slot offsets its GPU build ran with (fixture `slot_shift`, fitted on this image with the
+    oracle; the offset is a test-only knob of the C ABI, ptk_debug_slot_shift) — summed in iteration order, saveImage's transform in
+    numpy.  The device computes sin/cos by the ptk specification, the reference by CUDA's sinf/cosf (both <= 2 ulp): a different
+    last bit moves a Direct-lighting sample by ~1e-7 relative, which survives the 8-bit quantisation only on level boundaries.
+    Measured on MI355X: printed below; asserted >= 98.5 % of the lit plate pixels bit-identical, >= 99.5 % within one level
+    (the CPU oracle with libm trig: 99.39 % / 99.6 %)."""
+    g = _fixture()
+    table = g["slot_shift"].astype(np.int32)
+    s = ptk.Scene(SCENE)
+    assert (s.width, s.height, s.trace_depth) == (W, W, 8)
+    r = ptk.Renderer(s, MODES["Direct"])
+    acc = np.zeros((W, W, 3), np.float32)
+    try:
+        for it in range(1, 21):
+            one = np.zeros((W, W, 3), np.float32)
+            for k in np.unique(table[it]):
+                assert ptk.lib.ptk_debug_slot_shift(int(k)) == 0
+                assert ptk.lib.ptk_debug_clear_image() == 0
+                r.iterate(it)
+                rows = table[it] == k
+                one[rows] = r.image().reshape(W, W, 3)[rows]
+            acc += one
+    finally:
+        ptk.lib.ptk_debug_slot_shift(0)
+        r.close(); s.close()
+    out = save_transform(acc, 20)
+    exact, within1, n = _plate_match(out, g, "Direct20")
+    print(f"HIP path vs gallery/Direct20.png: {n} lit plate pixels, exact {exact:.4f}, within 1 level {within1:.4f}")
+    assert exact >= 0.985 and within1 >= 0.995, (exact, within1)

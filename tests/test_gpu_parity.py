@@ -51,7 +51,16 @@ CASES = [  # scene, res, depth, mode
     ("bunny_cornell.txt", (128, 128), 5, "BSDF"),     # threaded-BVH traversal, 10 000 triangles
     ("bunny_cornell.txt", (96, 96), 4, "MIS"),        # shadow rays through the BVH
     ("obj_test.txt", (96, 96), 4, "MIS"),             # 0 lights, default materials (black), cube.obj
+    # the reference's remaining loadable scene files, verbatim, with the assets they name
+    ("textureEnv_test.txt", (128, 128), 6, "BSDF"),   # testtexture.png albedo map on cubetex.obj + Newport_Loft_Ref.hdr ENV map (image.h:73-85, pathtrace.cu:303-311)
+    ("textureEnv_test.txt", (128, 128), 6, "MIS"),
+    ("textureEnv_test.txt", (96, 96), 4, "DIRECT"),
+    ("sphere.txt", (96, 96), 4, "BSDF"),              # obsolete material syntax: one sphere, default material, no light
+    ("sphere.txt", (96, 96), 4, "MIS"),
+    ("disney_test.txt", (128, 128), 6, "BSDF"),       # foreign scene grammar: what the reference's parser makes of it (2 primitives, no light)
+    ("disney_test.txt", (128, 128), 6, "MIS"),
 ]
+BLACK = ("obj_test.txt", "sphere.txt", "disney_test.txt")      # scenes without a light: the image is black by construction
 MODES = {"BSDF": 0, "DIRECT": 1, "MIS": 2}
 
 
@@ -170,7 +179,7 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
     r.close()
     bad = (img != ref).any(axis=1)
     assert not bad.any(), f"{int(bad.sum())} of {len(ref)} pixels differ; first {np.argwhere(bad)[:3].ravel()}"
-    if name != "obj_test.txt" and not (name == "cornell.txt" and mode == "DIRECT"):   # cube light: direct lighting is black by construction
+    if name not in BLACK and not (name == "cornell.txt" and mode == "DIRECT"):   # cube light: direct lighting is black by construction
         assert ref.sum() > 0
 
 
@@ -242,6 +251,39 @@ def test_sparse_tail(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
     img = r.image()
     assert r.ray_total() == rays
     r.close()
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_sample_mode_switch_resets_the_tail_hint(ptk, orc, torch_cuda, lanes):
+    """the number of full-width bounces is learnt from earlier iterations' live counts.  DIRECT paths all die after one
+    bounce, so after some DIRECT iterations everything past bounce 0 runs in the single-workgroup k_tail; a live switch to BSDF
+    (ptk_set_sample_mode, or the `sampleMode` global of the C++ API) must not send the hundred thousand paths per bounce BSDF keeps
+    alive through that one workgroup: the hint goes back to "every bounce at full width" at the switch and is learnt again.
+    Image and live counts == oracle across the switch, with one and three iterations in flight."""
+    name, res, depth = "cornell.txt", (256, 256), 8
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, ptk.MODE_DIRECTLI, in_flight=lanes, graph=lanes > 1)
+    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    it = 0
+    for _ in range(12):
+        it += 1; r.iterate(it); o.pathtrace(ptk.MODE_DIRECTLI, it, planes[(it - 1) % lanes])
+        r.sync()
+    assert r.full_width_bounces() == 1                      # DIRECT: counts[1] == 0, learnt within a few iterations
+    assert ptk.lib.ptk_set_sample_mode(ptk.MODE_BSDF) == 0
+    for k in range(12):
+        it += 1; r.iterate(it)
+        if k == 0:
+            assert r.full_width_bounces() == depth          # the first BSDF iteration is enqueued at full width again
+        _, live = o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+        counts, _ = r.live_counts()
+        assert np.array_equal(counts, live), (it, counts, live)
+    assert r.full_width_bounces() == depth                  # closed box: > 1024 paths alive at every bounce
+    ref = planes[0].copy()
+    for p in planes[1:]:
+        ref = ref + p
+    img = r.image(); r.close()
     assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
 
@@ -522,6 +564,9 @@ FULL = [  # BASELINE.json configs at full size (oracle: a few seconds per iterat
     ("bunny_cornell.txt", None, -1, "BSDF", 1),       # configs[2] timed scene: 800x800 depth 8, 10k triangles
     ("mis_test.txt", (1024, 1024), 16, "MIS", 2),     # configs[3]
     ("metallic_analytic.txt", (1024, 1024), 16, "MIS", 1),   # configs[3]'s "full BSDF set": MetallicWorkflow + Dielectric + Microfacet + Lambertian
+    ("textureEnv_test.txt", None, -1, "MIS", 2),      # the reference's textured / ENV-mapped scene at its own RES 800x800 DEPTH 12
+    ("sphere.txt", None, -1, "MIS", 1),               # at the file's own 800x800 depth 8
+    ("disney_test.txt", None, -1, "BSDF", 1),
 ]
 
 
@@ -540,6 +585,18 @@ def test_full_size_configs(ptk, orc, torch_cuda, name, res, depth, mode, iters):
     img = r.image(); r.close()
     bad = (img != ref).any(axis=1)
     assert not bad.any(), f"{int(bad.sum())} of {len(ref)} pixels differ"
+
+
+def test_reference_scene_without_camera_is_refused(ptk, torch_cuda):
+    """scenes/pbr_texture.txt (verbatim): its camera block is spelled `Camera`, which the reference's parser does not recognise, and
+    its ENV file is a missing blob — the loaders (product == oracle, tests/test_scene_host.py) end with a 0 x 0 frame, depth 0.
+    There is nothing to render; the render API says so instead of launching empty kernels."""
+    s = ptk.Scene(os.path.join(SC, "pbr_texture.txt"))
+    assert (s.width, s.height, s.trace_depth, s.n_geoms) == (0, 0, 0, 0)
+    with pytest.raises(ptk.PtkError) as e:
+        ptk.Renderer(s, ptk.MODE_MIS)
+    assert e.value.code == ptk.E_BADARG
+    ptk.lib.ptk_pathtrace_free()
 
 
 def test_benchmarked_configuration_full_size(ptk, orc, torch_cuda):
