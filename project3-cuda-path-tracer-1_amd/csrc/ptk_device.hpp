@@ -39,21 +39,138 @@ struct f3 { float x, y, z; };
 struct f2 { float x, y; };
 
 PTK_DI f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+typedef float ptk_v2f __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+// x and y of a 3-vector ride in one packed operation (v_pk_add/mul_f32: per-component IEEE), z in a scalar one: 2 instructions per 3-vector op
+PTK_DI f3 pk3(ptk_v2f xy, float z) { return mk3(xy.x, xy.y, z); }
+PTK_DI ptk_v2f xy_of(f3 a) { ptk_v2f r = {a.x, a.y}; return r; }
+PTK_DI f3 operator+(f3 a, f3 b) { return pk3(xy_of(a) + xy_of(b), a.z + b.z); }
+PTK_DI f3 operator-(f3 a, f3 b) { return pk3(xy_of(a) - xy_of(b), a.z - b.z); }
+PTK_DI f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PTK_DI f3 operator*(f3 a, f3 b) { return pk3(xy_of(a) * xy_of(b), a.z * b.z); }
+PTK_DI f3 operator*(f3 a, float s) { ptk_v2f ss = {s, s}; return pk3(xy_of(a) * ss, a.z * s); }
+PTK_DI f3 operator*(float s, f3 a) { ptk_v2f ss = {s, s}; return pk3(ss * xy_of(a), s * a.z); }
+#else
 PTK_DI f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 PTK_DI f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PTK_DI f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 PTK_DI f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PTK_DI f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 PTK_DI f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+#endif
 PTK_DI f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+
+// ---- exact fast paths for IEEE divide / sqrt ("same operations, fewer instructions") -----------------------------------------
+// The compiler expands a correctly rounded fp32 a / d into 11 instructions: v_div_scale x2 (operand pre-scaling), v_rcp, two
+// Newton steps on the reciprocal (e = fma(-d, y, 1); y = fma(e, y, y)), q = a * y, two residual corrections (r = fma(-d, q, a);
+// q = fma(r, y, q)), the last one as v_div_fmas, then v_div_fixup; and sqrtf into 16: a pre-scaling of tiny arguments, v_sqrt,
+// one step down / one step up tested with two exact residuals, the rescaling, a class test for 0 / inf.  The scaling and fix-up
+// steps are the identity when the operands are normal numbers of moderate magnitude — V_DIV_SCALE_F32 scales only when an operand
+// or the quotient or 1/d is (nearly) denormal, when the exponents differ by >= 96 or when the numerator's exponent is <= 23; the
+// sqrt prologue only below 2^-96 — so for operands in [2^-40, 2^40] (divide) / [2^-80, 2^80] (sqrt, 1/sqrt) the sequences
+// below, which are THE SAME OPERATIONS without those steps, return the same bits as `/` and sqrtf.  What that buys:
+//   * one reciprocal refinement shared by all numerators over one denominator (the two slab planes of an axis; bsdf.xyz / pdf);
+//   * the per-numerator steps as packed operations (v_pk_mul_f32 / v_pk_fma_f32 are per-component IEEE): x and y of a 3-vector,
+//     or two numerators, ride in one instruction;
+//   * 1 / sqrt(x) (normalize) under one range test instead of two special-case ladders.
+// Operands outside the range (zeros, denormals, huge, inf, NaN) take the plain `/` / sqrtf, i.e. the compiler's full expansion.
+// tests/test_gpu_exact_math.py compares every helper with `/` and sqrtf on the device, bit for bit, on ~1e8 operand sets including
+// the range edges.  On the host (oracle-side builds, the scene layer) the helpers ARE `/` and sqrtf.
+#define PTK_EX_LO 9.094947017729282e-13f        // 2^-40
+#define PTK_EX_HI 1.099511627776e12f            // 2^40
+#define PTK_EX_LO2 8.271806125530277e-25f       // 2^-80
+#define PTK_EX_HI2 1.2089258196146292e24f       // 2^80
+#if defined(__HIP_DEVICE_COMPILE__)
+PTK_DI ptk_v2f splat2(float s) { ptk_v2f r = {s, s}; return r; }
+PTK_DI ptk_v2f fma2(ptk_v2f a, ptk_v2f b, ptk_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+PTK_DI float rcp_refined(float d) { const float y = __builtin_amdgcn_rcpf(d); const float e = __builtin_fmaf(-d, y, 1.0f); return __builtin_fmaf(e, y, y); }
+PTK_DI ptk_v2f rcp_refined2(ptk_v2f d) {
+    ptk_v2f y = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const ptk_v2f e = fma2(-d, y, splat2(1.0f));
+    return fma2(e, y, y);
+}
+// the quotient steps of the expansion, given the refined reciprocal y of d
+PTK_DI float div_steps(float a, float d, float y) {
+    float q = a * y;
+    float r = __builtin_fmaf(-d, q, a); q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, a); return __builtin_fmaf(r, y, q);
+}
+PTK_DI ptk_v2f div_steps2(ptk_v2f a, ptk_v2f d, ptk_v2f y) {
+    ptk_v2f q = a * y;
+    ptk_v2f r = fma2(-d, q, a); q = fma2(r, y, q);
+    r = fma2(-d, q, a); return fma2(r, y, q);
+}
+PTK_DI float inv_steps(float d, float y) {          // 1.0f / d: the first product 1 * y is y itself
+    float r = __builtin_fmaf(-d, y, 1.0f); float q = __builtin_fmaf(r, y, y);
+    r = __builtin_fmaf(-d, q, 1.0f); return __builtin_fmaf(r, y, q);
+}
+PTK_DI float sqrt_steps(float x) {                  // x in [2^-96, FLT_MAX]
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float e_dn = __builtin_fmaf(-dn, s, x), e_up = __builtin_fmaf(-up, s, x);
+    float t = (e_dn <= 0.0f) ? dn : s;
+    t = (e_up > 0.0f) ? up : t;
+    return t;
+}
+PTK_DI bool ex_in(float x, float lo, float hi) { return x >= lo && x <= hi; }      // false for NaN
+#endif
+// a / d
+PTK_DI float div_exact(float a, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ex_in(__builtin_fabsf(a), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d), PTK_EX_LO, PTK_EX_HI)) return div_steps(a, d, rcp_refined(d));
+#endif
+    return a / d;
+}
+// 1 / d
+PTK_DI float inv_exact(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ex_in(__builtin_fabsf(d), PTK_EX_LO, PTK_EX_HI)) return inv_steps(d, rcp_refined(d));
+#endif
+    return 1.0f / d;
+}
+// sqrtf(x)
+PTK_DI float sqrt_exact(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ex_in(x, PTK_EX_LO2, PTK_EX_HI2)) return sqrt_steps(x);
+#endif
+    return sqrtf(x);
+}
+// 1 / sqrtf(x) (two correctly rounded steps, as glm::normalize / inversesqrt do it)
+PTK_DI float inv_sqrt_exact(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ex_in(x, PTK_EX_LO2, PTK_EX_HI2)) { const float s = sqrt_steps(x); return inv_steps(s, rcp_refined(s)); }
+#endif
+    return 1.0f / sqrtf(x);
+}
+// (a.x / d, a.y / d, a.z / d)
+PTK_DI f3 div3_exact(f3 a, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // explicit range compares, each false for a NaN (min / max chains are not NaN-safe: in IEEE mode a signalling NaN turns the partial
+    // result into a quiet NaN, which the next min / max drops together with the operands it had absorbed — found by k_exact_check)
+    if (ex_in(__builtin_fabsf(a.x), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(a.y), PTK_EX_LO, PTK_EX_HI) &&
+        ex_in(__builtin_fabsf(a.z), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d), PTK_EX_LO, PTK_EX_HI)) {
+        const float y = rcp_refined(d);
+        const ptk_v2f q = div_steps2(xy_of(a), splat2(d), splat2(y));
+        return mk3(q.x, q.y, div_steps(a.z, d, y));
+    }
+#endif
+    return mk3(a.x / d, a.y / d, a.z / d);
+}
+PTK_DI float dot(f3 a, f3 b);
+PTK_DI float length(f3 v) { return sqrt_exact(dot(v, v)); }
+PTK_DI f3 normalize(f3 v) { return v * inv_sqrt_exact(dot(v, v)); }              // glm: v * inversesqrt(dot(v, v)), inversesqrt = 1 / sqrt
 PTK_DI float gmin(float x, float y) { return x < y ? x : y; }          // glm::min
 PTK_DI float gmax(float x, float y) { return x > y ? x : y; }          // glm::max
 PTK_DI float smax(float a, float b) { return a < b ? b : a; }          // std::max
 PTK_DI float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+#if defined(__HIP_DEVICE_COMPILE__)
+PTK_DI float dot(f3 a, f3 b) { const ptk_v2f p = xy_of(a) * xy_of(b); return (p.x + p.y) + a.z * b.z; }      // (ax*bx + ay*by) + az*bz, the products packed
+#else
 PTK_DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+#endif
 PTK_DI f3 cross(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
-PTK_DI float length(f3 v) { return sqrtf(dot(v, v)); }
-PTK_DI f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+PTK_DI float length(f3 v);
+PTK_DI f3 normalize(f3 v);
 PTK_DI f3 reflect(f3 I, f3 N) { return I - N * dot(N, I) * 2.0f; }
 PTK_DI float mixf(float x, float y, float a) { return x + a * (y - x); }
 PTK_DI f3 mixv(f3 x, f3 y, float a) { return x + a * (y - x); }
@@ -235,6 +352,22 @@ PTK_DI DevGeomMask load_gmask_uniform(const DevGeomMask* base, int i) {
 }
 
 // vec3(M * vec4(v,1)) and vec3(M * vec4(v,0)) in glm's order (type_mat4x4.inl:617-628)
+#if defined(__HIP_DEVICE_COMPILE__)
+// rows 0 and 1 of the product ride in the two halves of packed operations (same products, same sums, same order per component)
+PTK_DI ptk_v2f mk2(float a, float b) { ptk_v2f r = {a, b}; return r; }
+PTK_DI f3 xform_point(const float* m, f3 v) {
+    const ptk_v2f r = (mk2(m[0], m[4]) * splat2(v.x) + mk2(m[1], m[5]) * splat2(v.y)) + (mk2(m[2], m[6]) * splat2(v.z) + mk2(m[3], m[7]));
+    return mk3(r.x, r.y, (m[8] * v.x + m[9] * v.y) + (m[10] * v.z + m[11]));
+}
+PTK_DI f3 xform_dir(const float* m, f3 v) {
+    const ptk_v2f r = (mk2(m[0], m[4]) * splat2(v.x) + mk2(m[1], m[5]) * splat2(v.y)) + mk2(m[2], m[6]) * splat2(v.z);
+    return mk3(r.x, r.y, (m[8] * v.x + m[9] * v.y) + (m[10] * v.z));
+}
+PTK_DI f3 xform_nrm(const float* m, f3 v) {
+    const ptk_v2f r = (mk2(m[0], m[3]) * splat2(v.x) + mk2(m[1], m[4]) * splat2(v.y)) + mk2(m[2], m[5]) * splat2(v.z);
+    return mk3(r.x, r.y, (m[6] * v.x + m[7] * v.y) + (m[8] * v.z));
+}
+#else
 PTK_DI f3 xform_point(const float* m, f3 v) {
     return mk3((m[0] * v.x + m[1] * v.y) + (m[2] * v.z + m[3]),
                (m[4] * v.x + m[5] * v.y) + (m[6] * v.z + m[7]),
@@ -250,20 +383,21 @@ PTK_DI f3 xform_nrm(const float* m, f3 v) {
                (m[3] * v.x + m[4] * v.y) + (m[5] * v.z),
                (m[6] * v.x + m[7] * v.y) + (m[8] * v.z));
 }
+#endif
 
 // Diagonal fast paths.  With exactly-zero off-diagonal entries, (m0*x + 0*y) + (0*z + m3) == m0*x + m3 and
 // (m0*x + 0*y) + 0*z == m0*x for finite x,y,z (adding +-0 changes at most the sign of a zero), so these return values
 // that compare == to the general forms above.  `diag` is wave-uniform (it comes from the SGPR-resident geom record).
 PTK_DI f3 xform_point_d(const float* m, f3 v, int diag) {
-    if (diag) return mk3(m[0] * v.x + m[3], m[5] * v.y + m[7], m[10] * v.z + m[11]);
+    if (diag) return mk3(m[0], m[5], m[10]) * v + mk3(m[3], m[7], m[11]);      // (x, y) packed, z scalar (operator* / operator+)
     return xform_point(m, v);
 }
 PTK_DI f3 xform_dir_d(const float* m, f3 v, int diag) {
-    if (diag) return mk3(m[0] * v.x, m[5] * v.y, m[10] * v.z);
+    if (diag) return mk3(m[0], m[5], m[10]) * v;
     return xform_dir(m, v);
 }
 PTK_DI f3 xform_nrm_d(const float* m, f3 v, int diag) {
-    if (diag) return mk3(m[0] * v.x, m[4] * v.y, m[8] * v.z);
+    if (diag) return mk3(m[0], m[4], m[8]) * v;
     return xform_nrm(m, v);
 }
 
@@ -294,17 +428,40 @@ PTK_DI GeomXf load_xf(const float* xf, int i, int diag) {
 // boxIntersectionTest, intersections.h:48-90.  Returns world-space distance or -1.
 // The normal is NOT computed here: `ns` receives the object-space vector n with N = normalize(invTranspose * n), so the
 // caller evaluates it once for the primitive that wins (the reference evaluates it for every candidate and discards it).
+// the six slab distances of the unit cube, t1 = (-0.5 - o) / d and t2 = (+0.5 - o) / d per axis (intersections.h:59-61): six correctly
+// rounded quotients over three denominators — x and y in packed steps, the two z planes as one pair over d.z
+PTK_DI void box_slabs(f3 o, f3 d, f3& t1, f3& t2) {
+    const f3 n1 = mk3(-0.5f, -0.5f, -0.5f) - o, n2 = mk3(0.5f, 0.5f, 0.5f) - o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Range test, every compare false for a NaN.  Numerators: |o| <= 2^39 bounds them above; below, -0.5 - o and 0.5 - o are exact
+    // next to 0 (Sterbenz), so a numerator is either 0 — when |o| == 0.5 — or at least 2^-25.
+    const float ox = __builtin_fabsf(o.x), oy = __builtin_fabsf(o.y), oz = __builtin_fabsf(o.z);
+    const bool num_ok = (ox <= 0.5f * PTK_EX_HI && ox != 0.5f) && (oy <= 0.5f * PTK_EX_HI && oy != 0.5f) && (oz <= 0.5f * PTK_EX_HI && oz != 0.5f);
+    const bool den_ok = ex_in(__builtin_fabsf(d.x), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d.y), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d.z), PTK_EX_LO, PTK_EX_HI);
+    if (num_ok && den_ok) {
+        const ptk_v2f dxy = xy_of(d), yxy = rcp_refined2(dxy);
+        const float yz = rcp_refined(d.z);
+        const ptk_v2f a = div_steps2(xy_of(n1), dxy, yxy), b = div_steps2(xy_of(n2), dxy, yxy);
+        const ptk_v2f c = div_steps2(mk2(n1.z, n2.z), splat2(d.z), splat2(yz));
+        t1 = mk3(a.x, a.y, c.x); t2 = mk3(b.x, b.y, c.y);
+        return;
+    }
+#endif
+    t1 = mk3(n1.x / d.x, n1.y / d.y, n1.z / d.z); t2 = mk3(n2.x / d.x, n2.y / d.y, n2.z / d.z);
+}
+
 template <class G>
 PTK_DI float box_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
     f3 qo = xform_point_d(g.inv, ro, g.diag);
     f3 qd = normalize(xform_dir_d(g.inv, rd, g.diag));
     float tmin = -1e38f, tmax = 1e38f;
     int amin = 0, amax = 0; float smin = 0.f, smax_ = 0.f;     // normal = axis * sign (zero-initialised tmin_n/tmax_n)
+    f3 s1, s2;
+    box_slabs(qo, qd, s1, s2);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float d = comp(qd, a), o = comp(qo, a);
-        float t1 = (-0.5f - o) / d;
-        float t2 = (+0.5f - o) / d;
+        float t1 = comp(s1, a);
+        float t2 = comp(s2, a);
         float ta = gmin(t1, t2), tb = gmax(t1, t2);
         float sg = t2 < t1 ? +1.f : -1.f;
         if (ta > 0 && ta > tmin) { tmin = ta; amin = a; smin = sg; }
@@ -328,7 +485,7 @@ PTK_DI float sphere_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
     float vd = dot(o, d);
     float radicand = vd * vd - (dot(o, o) - 0.25f);
     if (radicand < 0) return -1.f;
-    float sq = sqrtf(radicand);
+    float sq = sqrt_exact(radicand);
     float first = -vd;
     float t1 = first + sq, t2 = first - sq;
     float t;
@@ -475,7 +632,6 @@ struct Analytic { float t_min; int geom; f3 P, NS; };
 // miss, correct because the real primitive lies a margin inside.  Rays with NaN components never produce an accepted
 // hit in the exact test either (t > 0 fails).  Output: one bit per primitive of the chunk [base, base+n), n <= 32.
 struct Cand { unsigned cube, sphere, diag; };
-typedef float ptk_v2f __attribute__((ext_vector_type(2)));
 PTK_DI Cand analytic_candidates(const SceneView& S, int base, int n, f3 ro, f3 rd) {
     const float pr = PTK_CAND_REL * (1.0f + fmaxf(fabsf(ro.x), fmaxf(fabsf(ro.y), fabsf(ro.z))));
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -734,7 +890,7 @@ PTK_DI MatEval eval_material(const SceneView& S, const DevMaterial& m, f2 uv) {
 // ---- shading math ---------------------------------------------------------------------------------
 PTK_DI void pixar_basis(f3 n, f3& xp, f3& yp) {                   // utilities.h:188-200
     float sz = n.z >= 0 ? 1.f : -1.f;
-    float a = 1.0f / (sz + n.z);
+    float a = inv_exact(sz + n.z);
     float sx = sz * n.x;
     float b = n.x * n.y * a;
     xp = mk3(sx * n.x * a - 1.f, sz * b, sx);
@@ -743,7 +899,7 @@ PTK_DI void pixar_basis(f3 n, f3& xp, f3& yp) {                   // utilities.h
 PTK_DI f3 sample_hemisphere_cosine(f3 n, f2 r) {                  // utilities.h:224-235 + ONB 136-146
     f3 u, v; f3 w = normalize(n);
     pixar_basis(n, u, v);
-    float sinTheta = sqrtf(r.x), cosTheta = sqrtf(1 - r.x);
+    float sinTheta = sqrt_exact(r.x), cosTheta = sqrt_exact(1 - r.x);
     float sp, cp; sincos_ptk(PTK_TWO_PI * r.y, sp, cp);
     float lx = sinTheta * cp, ly = sinTheta * sp;
     return lx * u + ly * v + cosTheta * w;

@@ -706,7 +706,7 @@ __device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& g
     const f3 offsetDir = dot(s.dir, h.n) > 0 ? h.n : -h.n;
     p.d = s.dir;
     p.o = h.p + (isDelta ? 1e-3f * offsetDir : 1e-4f * s.dir);
-    p.col = p.col * (s.bsdf * fabsf(dot(s.dir, h.n)) / s.pdf);
+    p.col = p.col * div3_exact(s.bsdf * fabsf(dot(s.dir, h.n)), s.pdf);
     if (MODE == PTK_MODE_MIS) p.prevPdf = isDelta ? -1.f : s.pdf;
     int alive = 1;
     if (--p.bounces == 0) { p.col = mk3(0.f, 0.f, 0.f); alive = 0; }
@@ -1338,6 +1338,73 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_sum_planes(const float* __restric
     out[i] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// TEST-ONLY: the exact fast paths of ptk_device.hpp (div_exact / inv_exact / sqrt_exact / inv_sqrt_exact / div3_exact / box_slabs,
+// the packed dot / normalize / xform_*) against the plain IEEE forms (`/`, sqrtf, scalar arithmetic in glm's order), bit for bit,
+// on pseudo-random operand sets: any bit pattern, moderate magnitudes, the edges of the fast-path ranges (2^-40, 2^40, 2^-80, 2^80,
+// 2^-96), slab numerators next to zero.  bad[k] counts the mismatches of check k (NaN == NaN).  tests/test_gpu_exact_math.py.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float chk_operand(uint32_t h, int cls) {
+    const uint32_t mant = h & 0x7fffffu, sign = (h >> 31) << 31;
+    switch (cls) {
+    case 0: return __uint_as_float(h);                                                        // anything: NaN, inf, denormals, zeros
+    case 1: return __uint_as_float(sign | ((121u + ((h >> 23) & 15u)) << 23) | mant);         // 2^-6 .. 2^9
+    case 2: { const int e[8] = {-42, -41, -40, -39, 38, 39, 40, 41}; return __uint_as_float(sign | ((uint32_t)(127 + e[(h >> 23) & 7u]) << 23) | ((h >> 26) & 1u ? mant : 0u)); }
+    case 3: { const int e[8] = {-97, -96, -95, -81, -80, 79, 80, 81}; return __uint_as_float(sign | ((uint32_t)(127 + e[(h >> 23) & 7u]) << 23) | ((h >> 26) & 1u ? mant : 0u)); }
+    default: { const float base = (h >> 30) & 1u ? 0.5f : -0.5f;                              // next to a cube face: numerators near 0
+               return __uint_as_float(__float_as_uint(base) + ((h >> 23) & 7u) - 3u); }
+    }
+}
+__device__ __forceinline__ bool chk_same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+__global__ void __launch_bounds__(PTK_BLOCK) k_exact_check(unsigned long long n, uint32_t seed, unsigned long long* __restrict__ bad, uint32_t* __restrict__ samples) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = utilhash((uint32_t)i * 8u + (uint32_t)k + seed * 0x9e3779b9u) ^ utilhash((uint32_t)(i >> 29) + 77u * (uint32_t)k);
+    const int cls = (int)(utilhash((uint32_t)i + seed) % 5u);
+    const float a = chk_operand(h[0], cls), b = chk_operand(h[1], cls), c = chk_operand(h[2], cls), d = chk_operand(h[3], cls == 4 ? 1 : cls);
+    const float e = chk_operand(h[4], cls == 4 ? 1 : cls), f = chk_operand(h[5], cls == 4 ? 1 : cls);
+    unsigned m = 0u;
+    m |= chk_same(div_exact(a, d), a / d) ? 0u : 1u;
+    m |= chk_same(inv_exact(d), 1.0f / d) ? 0u : 2u;
+    const float pa = fabsf(a);
+    m |= chk_same(sqrt_exact(pa), sqrtf(pa)) ? 0u : 4u;
+    m |= chk_same(inv_sqrt_exact(pa), 1.0f / sqrtf(pa)) ? 0u : 8u;
+    { const f3 q = div3_exact(mk3(a, b, c), d);
+      m |= (chk_same(q.x, a / d) && chk_same(q.y, b / d) && chk_same(q.z, c / d)) ? 0u : 16u; }
+    { f3 t1, t2; box_slabs(mk3(a, b, c), mk3(d, e, f), t1, t2);
+      const bool ok = chk_same(t1.x, (-0.5f - a) / d) && chk_same(t1.y, (-0.5f - b) / e) && chk_same(t1.z, (-0.5f - c) / f) &&
+                      chk_same(t2.x, (0.5f - a) / d) && chk_same(t2.y, (0.5f - b) / e) && chk_same(t2.z, (0.5f - c) / f);
+      m |= ok ? 0u : 32u; }
+    { const f3 v = mk3(a, b, c), nv = normalize(v);
+      const float r = 1.0f / sqrtf(a * a + b * b + c * c);
+      m |= (chk_same(nv.x, a * r) && chk_same(nv.y, b * r) && chk_same(nv.z, c * r) && chk_same(length(v), sqrtf(a * a + b * b + c * c)) &&
+            chk_same(dot(v, mk3(d, e, f)), a * d + b * e + c * f)) ? 0u : 64u; }
+    { float mtx[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) mtx[k] = chk_operand(utilhash(h[6] + (uint32_t)k), 1);
+      const f3 v = mk3(a, b, c);
+      const f3 p = xform_point(mtx, v), q = xform_dir(mtx, v), r = xform_nrm(mtx, v), pd = xform_point_d(mtx, v, 1), qd = xform_dir_d(mtx, v, 1), rd = xform_nrm_d(mtx, v, 1);
+      bool ok = chk_same(p.x, (mtx[0] * a + mtx[1] * b) + (mtx[2] * c + mtx[3])) && chk_same(p.y, (mtx[4] * a + mtx[5] * b) + (mtx[6] * c + mtx[7])) &&
+                chk_same(p.z, (mtx[8] * a + mtx[9] * b) + (mtx[10] * c + mtx[11]));
+      ok = ok && chk_same(q.x, (mtx[0] * a + mtx[1] * b) + mtx[2] * c) && chk_same(q.y, (mtx[4] * a + mtx[5] * b) + mtx[6] * c) && chk_same(q.z, (mtx[8] * a + mtx[9] * b) + mtx[10] * c);
+      ok = ok && chk_same(r.x, (mtx[0] * a + mtx[1] * b) + mtx[2] * c) && chk_same(r.y, (mtx[3] * a + mtx[4] * b) + mtx[5] * c) && chk_same(r.z, (mtx[6] * a + mtx[7] * b) + mtx[8] * c);
+      ok = ok && chk_same(pd.x, mtx[0] * a + mtx[3]) && chk_same(pd.y, mtx[5] * b + mtx[7]) && chk_same(pd.z, mtx[10] * c + mtx[11]);
+      ok = ok && chk_same(qd.x, mtx[0] * a) && chk_same(qd.y, mtx[5] * b) && chk_same(qd.z, mtx[10] * c);
+      ok = ok && chk_same(rd.x, mtx[0] * a) && chk_same(rd.y, mtx[4] * b) && chk_same(rd.z, mtx[8] * c);
+      m |= ok ? 0u : 128u; }
+    if (m) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (m & (1u << k)) atomicAdd(&bad[k], 1ull);
+        if (samples) {                                   // the first failing operand sets, for the test's message: {mask, a..f}
+            const unsigned slot = atomicAdd(&samples[0], 1u);
+            if (slot < 15u) { uint32_t* r = samples + 8 * (slot + 1); r[0] = m; r[1] = __float_as_uint(a); r[2] = __float_as_uint(b); r[3] = __float_as_uint(c);
+                              r[4] = __float_as_uint(d); r[5] = __float_as_uint(e); r[6] = __float_as_uint(f); r[7] = (uint32_t)cls; }
+        }
+    }
+}
+
 inline int grid_for(int n) { return (n + PTK_BLOCK - 1) / PTK_BLOCK; }
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 inline int launch_rc() { return hip_rc(hipGetLastError()); }
@@ -1654,6 +1721,25 @@ int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char*
     const int P = res_x * res_y;
     k_tonemap<<<grid_for(P), PTK_BLOCK, 0, (hipStream_t)stream>>>(img, P, iter, reinterpret_cast<uchar4*>(pbo));
     return launch_rc();
+}
+
+/* test-only: see k_exact_check.  bad8 (host): mismatch counts of the 8 checks over n pseudo-random operand sets */
+int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long* bad8, unsigned* samples128) {
+    if (!bad8 || n == 0 || n > (1ull << 36)) return PTK_E_BADARG;
+    unsigned long long* d = nullptr;
+    hipError_t e = hipMalloc(&d, 8 * sizeof(unsigned long long) + 128 * sizeof(unsigned)); if (e != hipSuccess) return (int)e;
+    if ((e = hipMemset(d, 0, 8 * sizeof(unsigned long long) + 128 * sizeof(unsigned))) != hipSuccess) { (void)hipFree(d); return (int)e; }
+    uint32_t* smp = reinterpret_cast<uint32_t*>(d + 8);
+    const unsigned long long chunk = 1ull << 28;                      // bounded launches: a grid of 2^20 blocks each
+    for (unsigned long long done = 0; done < n; done += chunk) {
+        const unsigned long long m = n - done < chunk ? n - done : chunk;
+        k_exact_check<<<(unsigned)((m + PTK_BLOCK - 1) / PTK_BLOCK), PTK_BLOCK>>>(m, seed + (unsigned)(done >> 28) * 7919u, d, smp);
+        if ((e = hipGetLastError()) != hipSuccess) { (void)hipFree(d); return (int)e; }
+    }
+    e = hipMemcpy(bad8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && samples128) e = hipMemcpy(samples128, smp, 128 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return hip_rc(e);
 }
 
 #ifdef PTK_PHASE_TIMING

@@ -1,0 +1,13 @@
+"""GPU box: prints the first operand sets on which an exact fast path differs from the IEEE form (ptk_debug_exact_math)."""
+import ctypes as C, importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+torch.cuda.set_device(0)
+ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
+for seed in (1, 2):
+    bad = np.zeros(8, np.uint64); smp = np.zeros(128, np.uint32)
+    rc = ptk.lib.ptk_debug_exact_math(C.c_ulonglong(1 << 28), seed, bad.ctypes.data, smp.ctypes.data)
+    print("seed", seed, "rc", rc, "bad", bad.tolist())
+    for r in smp[8:8 + 8 * min(int(smp[0]), 15)].reshape(-1, 8):
+        print("  mask %#x cls %d" % (r[0], r[7]), " ".join("%.9g(%#010x)" % (float(np.uint32(x).view(np.float32)), x) for x in r[1:7]))
