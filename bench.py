@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--bvh-scene", default="bunny_cornell.txt", help="second roofline measurement on a BVH scene ('' = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="ptk_set_pipeline value (A/B comparisons)")
+    ap.add_argument("--lean", type=int, default=0, help="1: only the headline run and the roofline pass (no reference_order / cpu_baseline / BVH scene / contracted child)")
     return ap.parse_args()
 
 
@@ -360,7 +361,7 @@ def main():
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
         roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)
         extra = {}
-        if N == 1 and a.bvh_scene and a.bvh_scene != a.scene:
+        if N == 1 and not a.lean and a.bvh_scene and a.bvh_scene != a.scene:
             # the HBM-fraction target is only meaningful where the kernel streams BVH data: same measurement
             # on the BASELINE configs[2] timed scene (bunny_cornell.txt, 800x800 depth 8)
             bs = ptk.Scene(os.path.join(ROOT, "scenes", a.bvh_scene))
@@ -376,7 +377,7 @@ def main():
             extra["roofline_bvh_scene"] = dict(roofline_of(bs, *pb, a.profile_steps, a.bvh_scene), workload=f"scenes/{a.bvh_scene} {bs.width}x{bs.height} depth {bs.trace_depth}",
                                                mrays_per_s=round(brays / bms / 1e3, 1))
         ref_order = None
-        if N == 1 and (a.in_flight != 1 or a.graph):
+        if N == 1 and not a.lean and (a.in_flight != 1 or a.graph):
             # the reference's own schedule: one iteration at a time, eager launches -> its float accumulation order exactly
             # (the headline overlaps `in_flight` iterations: image = ((p0 + p1) + p2), each iteration itself unchanged)
             rr = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=1, graph=False)
@@ -390,8 +391,28 @@ def main():
             ref_order = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(1e3 * tt / a.steps, 4), "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
                          "config": "iterations_in_flight 1, graph_replay false: the reference's accumulation order, bit-identical image"}
         cpu = None
-        if N == 1 and a.cpu_seconds > 0:
+        if N == 1 and not a.lean and a.cpu_seconds > 0:
             cpu = cpu_baseline(scene_path, res, a.depth, mode, a.cpu_seconds)
+        contracted = None
+        if N == 1 and not a.lean and ptk.FLAVOUR == "exact" and os.path.exists(os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "libptk_fma.so")):
+            # the opt-in "reference-device numerics" flavour (libptk_fma.so: -ffp-contract=fast like nvcc's -fmad=true), same workload, own
+            # process (one flavour per process), reported beside the bit-exact headline, never instead of it
+            import subprocess
+            try:
+                c = subprocess.run([sys.executable, os.path.abspath(__file__), "--lean", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--scene", a.scene,
+                                    "--mode", a.mode, "--in-flight", str(a.in_flight), "--graph", str(a.graph), "--iters-per-step", str(IPS), "--profile-steps", str(a.profile_steps)]
+                                   + (["--res", str(res[0]), str(res[1])] if res else []) + (["--depth", str(a.depth)] if a.depth >= 0 else []),
+                                   env=dict(os.environ, PTK_FLAVOUR="fma"), capture_output=True, text=True, timeout=600)
+                cj = json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
+                pm = (pmc_record(a.scene) or {}).get("contracted_fma") or {}
+                contracted = {"value": cj["value"], "unit": "Mrays/s", "ms_per_iteration": cj["ms_per_iteration"], "frac": cj["roofline"]["frac"],
+                              "frac_note": "k_intersect, same algorithmic bytes / HIP-event launch time as roofline.frac",
+                              "valu_per_wave": pm.get("valu_per_launched_wave"), "valu_per_wave_exact": pm.get("valu_per_launched_wave_exact"),
+                              "flavour": cj.get("flavour"),
+                              "note": "libptk_fma.so = the same sources with -ffp-contract=fast (IEEE divide / sqrt kept); not bit-comparable with the oracle, "
+                                      "held to SURVEY 8(d)'s tolerances by tests/test_gpu_contracted.py"}
+            except Exception as e:       # the flavour is optional: its absence never fails the headline
+                contracted = {"error": str(e)[:200]}
         out = {
             "metric": "Mrays/s (paths x bounces / s)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
@@ -410,7 +431,7 @@ def main():
             "overlap_note": (f"{a.in_flight} iterations in flight on {a.in_flight} streams: ms_per_step is smaller than the sum of the "
                              "per-kernel times of one iteration (roofline.note) because iterations overlap") if a.in_flight > 1 else None,
             "reference_order": ref_order,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "contracted": contracted, "flavour": ptk.FLAVOUR,
         }
         if multi is not None:
             out["multi_gpu"] = multi

@@ -19,7 +19,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libptk.so")
+# PTK_FLAVOUR=fma selects the opt-in "reference-device numerics" build (libptk_fma.so: -ffp-contract=fast, like nvcc's -fmad=true);
+# anything else is the default bit-exact library.  One flavour per process (the library holds the render context).
+FLAVOUR = "fma" if os.environ.get("PTK_FLAVOUR", "") == "fma" else "exact"
+LIB_PATH = os.path.join(CSRC, "libptk_fma.so" if FLAVOUR == "fma" else "libptk.so")
 REPO_ROOT = os.path.dirname(_HERE)
 SCENES = os.path.join(REPO_ROOT, "scenes")
 
@@ -51,7 +54,7 @@ class PtkError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libptk.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC, "libptk.so", "ptk_headless"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", CSRC, "libptk.so", "libptk_fma.so", "ptk_headless"], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:], r.stderr[-4000:])
     if r.returncode != 0:
