@@ -139,6 +139,8 @@ def cpu_baseline(scene_path, res, depth, mode, seconds):
 def measure_kernels(ptk, scene, mode, pipeline, steps):
     """Untimed diagnostic pass on ONE stream (no overlap): per-kernel device time from HIP events on the render stream, plus
     BVH traversal statistics for scenes with triangles."""
+    if pipeline in (0, 10):
+        pipeline = 8            # the staged kernels: k_intersect on its own (SURVEY 8d's 76 B / ray figure is defined on it)
     r = ptk.Renderer(scene, mode, pipeline=pipeline, in_flight=1, graph=False)
     for it in (1, 2):
         r.iterate(it)

@@ -220,22 +220,25 @@ int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
 /* Pipeline selection (A/B comparisons; all produce identical results):
- *   0 = default.  Per bounce: intersect stage, shading with block-local compaction of the survivors, window prefix
- *       (k_segments); the next bounce addresses paths through the window tables, so surviving path state is written once
- *       and never moved.  Scenes with triangles run the work-list BVH layout in the intersect stage (analytic primitives +
- *       root-box test, stable compaction of the rays that enter the root box, BVH walk over the list, finalize);
- *   1 = like 0, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
+ *   0 = default (10 = the same, explicitly).  One launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d for the
+ *       survivors while their new rays are still in registers (the first launch of an iteration generates the camera rays
+ *       instead of shading); path state and hit record are written together at the survivor's slot in its block's window, the
+ *       compacted slot of a hit path (the reference's RNG key) is hit_pref[window] + its rank among the window's hits, and the last
+ *       block of every launch builds the window tables.  Scenes with triangles continue each launch with the work-list BVH stage
+ *       (stable compaction of the rays that enter the root box, BVH walk over the list, finalize).  While the traversal counters
+ *       are enabled the staged kernels of 8 run instead (they keep the counters);
+ *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the
+ *       survivors, and the window prefix in a separate one-block k_segments launch (7) or in the last block of the shading kernel (8);
+ *   1 = like 7, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
  *   2 = like 1, and analytic primitives are tested with wave-uniform loops over every primitive instead of the LDS-staged
  *       candidate pair lists;
- *   3 = fused: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans with
+ *   3 = ticketed fusion: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans with
  *       ticketed block ids; the hit record never leaves registers).  Least memory traffic, but the ticket counter
  *       serialises block starts (~11 ns each): slower than 0 on MI355X at the BASELINE sizes;
- *   4 = like 0 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables;
- *   5 = like 0, the work-list rays walk the reference's threaded 6-direction BVH, one ray per lane (0 walks the 8-wide
- *       collapsed form of the same tree, four lanes per ray, csrc/wide_bvh.h); 6 = the wide walk, explicitly;
- *   7 / 8 = like 0 with the window bookkeeping in a separate one-block k_segments launch / in the last block of the
- *       shading kernel (0 picks 8 with several iterations in flight, 7 with one);
- *   9 = like 0, every bounce launched at full width (0 finishes the sparse end of an iteration in one single-workgroup
+ *   4 = like 7 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables;
+ *   5 = like 7/8, the work-list rays walk the reference's threaded 6-direction BVH, one ray per lane (the others walk the 8-wide
+ *       collapsed form of the same tree, several lanes per ray, csrc/wide_bvh.h); 6 = the wide walk with the staged kernels;
+ *   9 = like 7/8, every bounce launched at full width (0, 7 and 8 finish the sparse end of an iteration in one single-workgroup
  *       k_tail launch once earlier iterations have shown that few paths survive). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);

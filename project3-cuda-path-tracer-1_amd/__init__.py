@@ -21,8 +21,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # PTK_FLAVOUR=fma selects the opt-in "reference-device numerics" build (libptk_fma.so: -ffp-contract=fast, like nvcc's -fmad=true);
 # anything else is the default bit-exact library.  One flavour per process (the library holds the render context).
-FLAVOUR = "fma" if os.environ.get("PTK_FLAVOUR", "") == "fma" else "exact"
-LIB_PATH = os.path.join(CSRC, "libptk_fma.so" if FLAVOUR == "fma" else "libptk.so")
+FLAVOUR = os.environ.get("PTK_FLAVOUR", "") or "exact"       # "fma", or the name of a diagnostic build libptk_<name>.so (tools/diag)
+if FLAVOUR != "exact" and not os.path.exists(os.path.join(CSRC, f"libptk_{FLAVOUR}.so")):
+    FLAVOUR = "exact"
+LIB_PATH = os.path.join(CSRC, "libptk.so" if FLAVOUR == "exact" else f"libptk_{FLAVOUR}.so")
 REPO_ROOT = os.path.dirname(_HERE)
 SCENES = os.path.join(REPO_ROOT, "scenes")
 

@@ -31,7 +31,8 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     PtkPaths bufA = {nullptr, nullptr, nullptr}, bufB = {nullptr, nullptr, nullptr};
-    PtkHits hits = {nullptr, nullptr, nullptr};
+    PtkHits hits = {nullptr, nullptr, nullptr}, hitsB = {nullptr, nullptr, nullptr};     // hitsB, hrA/hrB: fused pipeline (hit records ping-pong with the paths)
+    int* hrA = nullptr; int* hrB = nullptr;
     Workspace ws;
     float* plane = nullptr;             // float[3*P] radiance sum of this lane's iterations (points into RenderContext::planes)
     int last_iter = 0;
@@ -96,6 +97,8 @@ int context_free() {
     for (Lane& l : g.lanes) {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
+        dfree(l.hitsB.t_n); dfree(l.hitsB.p_mat); dfree(l.hitsB.uv_ids); dfree(l.hrA); dfree(l.hrB);
+        dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
         dfree(l.ws.ticket); dfree(l.ws.epoch); dfree(l.ws.st_hit); dfree(l.ws.st_live);
@@ -124,9 +127,11 @@ int context_free() {
 // Window bookkeeping of the segmented streams: by the shading kernel's last block (pipeline 8, default with several iterations in
 // flight: one launch less per bounce, +2 % on the headline) or by a separate one-block k_segments launch (pipeline 7, default with
 // one iteration at a time, where the serial tail of that last block costs more than the launch: 0.352 vs 0.363 ms per iteration).
+// Pipeline 0 / 10: the fused k_shade_trace launches (one per bounce); they always do their own window bookkeeping.
+static bool trace_pipeline(int pipeline) { return pipeline == 0 || pipeline == 10; }
 static bool fold_segments(int pipeline, int n_lanes) {
     if (pipeline == 7) return false;
-    if (pipeline == 8) return true;
+    if (pipeline == 8 || trace_pipeline(pipeline)) return true;
     return n_lanes > 1;
 }
 static int pick_walk(int pipeline, int n_lanes) {
@@ -151,7 +156,17 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.p_mat, 4 * (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.hits.uv_ids, 4 * (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.hitsB.t_n, 4 * (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.hitsB.p_mat, 4 * (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.hitsB.uv_ids, 4 * (size_t)g.capacity))) return rc;
+    const size_t slots = ((size_t)g.capacity + 255) / 256 * 256 + 256;          // physical slots: whole 256-slot windows
+    if ((rc = dalloc(&l.hrA, slots))) return rc;
+    if ((rc = dalloc(&l.hrB, slots))) return rc;
+    if ((rc = dalloc(&l.ws.tr_valid, slots))) return rc;
+    if ((rc = dalloc(&l.ws.tr_heavy, slots))) return rc;
     const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;
+    if ((rc = dalloc(&l.ws.agg_h, blocks))) return rc;
+    if ((rc = dalloc(&l.ws.hit_pref, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.agg_a, blocks))) return rc;
     if ((rc = dalloc(&l.ws.agg_b, blocks))) return rc;
     if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
@@ -246,9 +261,12 @@ void prof_mark(int cls, bool begin) {
     if (begin) g_prof.cls.push_back(cls);
 }
 
-// k_tail finishes the iterations of the default (segmented, staged) pipelines; pipeline 9 = every bounce at full width (A/B)
+// k_tail finishes the iterations of the default (segmented) pipelines; pipeline 9 = every bounce at full width (A/B)
 bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 3 && g.pipeline != 4 && g.pipeline != 1 && g.pipeline != 2 && !g_prof.on &&
                             !(g.lanes.size() && g.lanes[0].ws.stats); }
+// the fused shade + trace launches (default); the traversal counters are only kept by the staged kernels
+bool use_trace_pipeline() { return trace_pipeline(g.pipeline) && !(g.lanes.size() && g.lanes[0].ws.stats); }
+void no_mark(int, bool) {}
 
 int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     const Camera& cam = g.scene->state.camera;
@@ -257,12 +275,30 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
     ws.iter_stride = g.n_lanes * g.n_shards;
     ws.slot_bias += g_debug_slot_shift;
+    const int full = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
+    if (use_trace_pipeline()) {
+        // launch 0 generates the camera rays and traces bounce 0; launch dt shades bounce dt - 1 and traces bounce dt (k_shade_trace)
+        void (*mark)(int, bool) = g_prof.on ? prof_mark : no_mark;
+        TraceBufs A = {L.bufA, L.hits, L.hrA}, B = {L.bufB, L.hitsB, L.hrB};
+        TraceBufs *cur = &A, *nxt = &B;
+        int rc = launch_shade_trace(S, mode, true, cam, g.n_parts, g.part, g.tile_rows, g.n_pix, g.traceDepth, iter, 0, g.capacity, A, A, L.plane, ws, L.stream, false, mark);
+        for (int dt = 1; dt <= full && !rc; ++dt) {
+            rc = launch_shade_trace(S, mode, false, cam, g.n_parts, g.part, g.tile_rows, g.n_pix, g.traceDepth, iter, dt, g.capacity, *cur, *nxt, L.plane, ws, L.stream,
+                                    dt == g.traceDepth, mark);
+            std::swap(cur, nxt);
+        }
+        if (!rc && full < g.traceDepth) {            // the sparse rest of the iteration in one single-workgroup launch; bounce `full` is traced already
+            prof_mark(1, true);
+            rc = launch_tail(S, mode, iter, full, g.traceDepth, cur->paths, nxt->paths, L.plane, ws, L.stream, &cur->hits, cur->hr);
+            prof_mark(1, false);
+        }
+        return rc;
+    }
     prof_mark(0, true);
     int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, g.n_parts, g.part, g.tile_rows, g.n_pix, g.spp, ws.counts, L.stream);
     prof_mark(0, false);
     if (rc) return rc;
     PtkPaths cur = L.bufA, nxt = L.bufB;
-    const int full = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
     for (int depth = 0; depth < full; ++depth) {
         const bool last = depth == g.traceDepth - 1;      // false for every full-width bounce when k_tail follows: it steps the iteration number
         if (ws.fused) {
@@ -549,7 +585,7 @@ int ptk_debug_clear_image(void) {
     return rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
 }
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 9) return PTK_E_BADARG;
+    if (which < 0 || which > 10) return PTK_E_BADARG;
     g.pipeline = which;
     for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which < 4); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);

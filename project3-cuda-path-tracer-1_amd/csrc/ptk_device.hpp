@@ -112,7 +112,11 @@ PTK_DI float sqrt_steps(float x) {                  // x in [2^-96, FLT_MAX]
     t = (e_up > 0.0f) ? up : t;
     return t;
 }
+#ifdef PTK_EX_NOFALLBACK      // TIMING EXPERIMENTS ONLY (tools/diag): the range tests compiled out; never shipped
+PTK_DI bool ex_in(float, float, float) { return true; }
+#else
 PTK_DI bool ex_in(float x, float lo, float hi) { return x >= lo && x <= hi; }      // false for NaN
+#endif
 #endif
 // a / d
 PTK_DI float div_exact(float a, float d) {
@@ -436,7 +440,11 @@ PTK_DI void box_slabs(f3 o, f3 d, f3& t1, f3& t2) {
     // Range test, every compare false for a NaN.  Numerators: |o| <= 2^39 bounds them above; below, -0.5 - o and 0.5 - o are exact
     // next to 0 (Sterbenz), so a numerator is either 0 — when |o| == 0.5 — or at least 2^-25.
     const float ox = __builtin_fabsf(o.x), oy = __builtin_fabsf(o.y), oz = __builtin_fabsf(o.z);
+#ifdef PTK_EX_NOFALLBACK
+    const bool num_ok = true; (void)ox; (void)oy; (void)oz;
+#else
     const bool num_ok = (ox <= 0.5f * PTK_EX_HI && ox != 0.5f) && (oy <= 0.5f * PTK_EX_HI && oy != 0.5f) && (oz <= 0.5f * PTK_EX_HI && oz != 0.5f);
+#endif
     const bool den_ok = ex_in(__builtin_fabsf(d.x), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d.y), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d.z), PTK_EX_LO, PTK_EX_HI);
     if (num_ok && den_ok) {
         const ptk_v2f dxy = xy_of(d), yxy = rcp_refined2(dxy);

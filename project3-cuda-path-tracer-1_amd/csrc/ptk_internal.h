@@ -67,6 +67,8 @@ struct Workspace {               // per-render-context scratch, device memory
                                  // a separate k_segments launch does the bookkeeping (pipeline 7, A/B)
     bool segmented = true;       // false: k_scatter moves the survivors (pipeline 4)
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
+    // fused pipeline (k_shade_trace): per-window hit counts and their prefix, the SPLIT stage's per-slot flags
+    int* agg_h = nullptr; int* hit_pref = nullptr; int* tr_valid = nullptr; int* tr_heavy = nullptr;
     int wide_lpr = 4;            // lanes per ray of the wide walk (4 or 2; ptk_kernels.hip k_traverse_wide)
     int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)
     int capacity = 0;
@@ -81,7 +83,12 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
 int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img,
                         const Workspace& ws, hipStream_t st, bool last_bounce);
 int launch_tail(const SceneView& S, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
-                const Workspace& ws, hipStream_t st);
+                const Workspace& ws, hipStream_t st, const PtkHits* hits0 = nullptr, const int* hr0 = nullptr);
+// fused pipeline (k_shade_trace): shade bounce dt - 1 of `cur` (gen: generate the camera rays instead) and trace bounce dt into `nxt`
+struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; };
+int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
+                       int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
+                       bool last, void (*mark)(int, bool));
 void set_fused_block(int nt);
 void set_shade_bin(int nt);
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);

@@ -83,6 +83,38 @@ __device__ __forceinline__ int prior_blocks(const int* __restrict__ agg, int b) 
     return t;
 }
 
+// exclusive prefix of agg[0 .. nw) into out[0 .. nw], out[nw .. nw + 8) = total (one block; AGENT as in segments_block)
+template <int NT, bool AGENT>
+__device__ __forceinline__ int prefix_block(int nw, const int* __restrict__ agg, int* __restrict__ out) {
+    constexpr int NW = NT / 64;
+    __shared__ int s_w[NW];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nw; base += NT) {
+        const int idx = base + tid;
+        int v = 0;
+        if (idx < nw) v = AGENT ? __hip_atomic_load(agg + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : agg[idx];
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_w[wid] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int cw = s_w[w]; woff += (w < wid) ? cw : 0; tot += cw; }
+        const int carry = s_carry;
+        if (idx < nw) out[idx] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    const int total = s_carry;
+    if (tid < 8) out[nw + tid] = total;
+    return total;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
 __device__ __forceinline__ void st4(float* p, int i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
 
@@ -125,19 +157,26 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
 // reference's "first in index order among equal distances" (strict t_min > t, pathtrace.cu:228), for any pair order;
 // t > 0 floats order like their bit patterns.  After a barrier the thread whose key is the ray's minimum stores the hit
 // point and the deferred normal for it (a later round can only lower the key, and then overwrites).
-template <int NT>
-__device__ __forceinline__ void analytic_closest_block(const SceneView& S, const GeomStage& gs, bool active, f3 ro, f3 rd, Analytic& a) {
+// LDS the block-cooperative closest-hit search works in (24.1 KB for 256 threads)
+struct TraceLds {
+    float4* ray;                 // [2 * NT]  origin, direction of the block's rays
+    float2* res;                 // [3 * NT]  winner's hit point + deferred normal, 24 B per ray (with 32 B the block's static LDS crosses
+                                 //           160 KB / 6: five blocks per CU instead of six)
+    unsigned long long* best;    // [NT]
+    unsigned short* list;        // [NT * 16] pair list
+    int* cnt;                    // [NT / 64]
+};
+// RAYS_IN_LDS: L.ray already holds the rays (written by other threads of the block, a barrier since); else every thread stores its own
+template <int NT, bool RAYS_IN_LDS>
+__device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, bool active, f3 ro, f3 rd, Analytic& a) {
     constexpr int NW = NT / 64;
     constexpr int RB = NT == 512 ? 9 : 8;                 // bits of the ray index inside a list entry
-    __shared__ float4 s_ray[2 * NT];                      // origin, direction
-    __shared__ float2 s_res[3 * NT];                      // winner's hit point + deferred normal, 24 B per ray (with 32 B the block's
-                                                          // static LDS crosses 160 KB / 6: five blocks per CU instead of six)
-    __shared__ unsigned long long s_best[NT];
-    __shared__ unsigned short s_list[NT * 16];
-    __shared__ int s_cnt[NW];
+    float4* s_ray = L.ray; float2* s_res = L.res; unsigned long long* s_best = L.best; unsigned short* s_list = L.list; int* s_cnt = L.cnt;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    s_ray[2 * tid] = make_float4(ro.x, ro.y, ro.z, 0.f);
-    s_ray[2 * tid + 1] = make_float4(rd.x, rd.y, rd.z, 0.f);
+    if (!RAYS_IN_LDS) {
+        s_ray[2 * tid] = make_float4(ro.x, ro.y, ro.z, 0.f);
+        s_ray[2 * tid + 1] = make_float4(rd.x, rd.y, rd.z, 0.f);
+    }
     s_best[tid] = ~0ull;
     for (int base = 0; base < S.n_geoms; base += 32) {
         const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
@@ -201,6 +240,16 @@ __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const
         a.t_min = __uint_as_float((unsigned)(best >> 32)); a.geom = (int)(unsigned)best;
         a.P = mk3(r0.x, r0.y, r1.x); a.NS = mk3(r1.y, r2.x, r2.y);
     }
+}
+template <int NT>
+__device__ __forceinline__ void analytic_closest_block(const SceneView& S, const GeomStage& gs, bool active, f3 ro, f3 rd, Analytic& a) {
+    __shared__ float4 s_ray[2 * NT];
+    __shared__ float2 s_res[3 * NT];
+    __shared__ unsigned long long s_best[NT];
+    __shared__ unsigned short s_list[NT * 16];
+    __shared__ int s_cnt[NT / 64];
+    const TraceLds L = {s_ray, s_res, s_best, s_list, s_cnt};
+    analytic_closest_lds<NT, false>(S, gs, L, active, ro, rd, a);
 }
 
 // Segmented path streams (default render pipeline).  The shading kernel writes the survivors of its block contiguously at
@@ -353,8 +402,9 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
 
 // stable compaction of the flagged ray indices into the traversal work list (same scheme as k_scatter, 4-byte payload)
 __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
-                                                     const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count) {
-    const int n = d_n ? *d_n : n_arg;
+                                                     const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count, int whole_windows) {
+    int n = d_n ? *d_n : n_arg;
+    if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;      // fused pipeline: flags live at physical slots, every slot of a window is written
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0) *list_count = 0u; return; }
     const int i = b * PTK_BLOCK + threadIdx.x;
@@ -600,6 +650,46 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
         (void)block_excl_prefix(flag, total);
         if (threadIdx.x == 0) agg[b] = total;
     }
+}
+
+// k_finalize of the fused pipeline: slots are physical, every slot of the windows [0, ceil(n / 256)) carries valid = -2 (empty) / 0 / 1 /
+// PTK_VALID_TRI; writes the hit rank of every slot (hr: >= 0 rank among the hits of its window, -1 miss, -2 empty) and the window's
+// hit count, from which k_hit_prefix builds hit_pref (a triangle hit changes the ranks the shading keys are made of).
+__global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits, const int* __restrict__ valid,
+                                                          int* __restrict__ hr, int* __restrict__ agg_h) {
+    const int n = d_n ? *d_n : n_arg;
+    const int b = blockIdx.x;
+    if (b * PTK_BLOCK >= n) return;
+    const int i = b * PTK_BLOCK + threadIdx.x;
+    const int flag = valid[i];
+    if (flag == PTK_VALID_TRI) {
+        const float4 r = ld4(hits.uv_ids, i);
+        Hit h;
+        triangle_record(S, __float_as_int(r.w), r.x, r.y, r.z, h);
+        st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+        st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+        if (!S.slim_hits) st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+    }
+    int total;
+    const int rank = block_excl_prefix(flag >= 1 ? 1 : 0, total);
+    hr[i] = flag >= 1 ? rank : (flag == 0 ? -1 : -2);
+    if (threadIdx.x == 0) agg_h[b] = total;
+}
+__global__ void __launch_bounds__(1024) k_hit_prefix(int n_arg, const int* __restrict__ d_n, const int* __restrict__ agg_h, int* __restrict__ hit_pref) {
+    const int n = d_n ? *d_n : n_arg;
+    (void)prefix_block<1024, false>(n > 0 ? (n + PTK_BLOCK - 1) / PTK_BLOCK : 0, agg_h, hit_pref);
+}
+// environment map on a miss, fused pipeline: slot g of the traced stream missed iff hr[g] == -1
+__global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths, const int* __restrict__ hr,
+                                                          float* __restrict__ img, unsigned plane_stride) {
+    const int n = d_n ? *d_n : n_arg;
+    const int g = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (blockIdx.x * PTK_BLOCK >= n || hr[g] != -1) return;
+    const float4 d4 = ld4(paths.d_bnc, g), c4 = ld4(paths.col_pdf, g);
+    const int pix = __float_as_int(paths.o_pix[4 * (size_t)g + 3]);
+    const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
+    float* p = img + (size_t)(pix >> 24) * plane_stride + 3 * (size_t)(pix & 0xFFFFFF);
+    p[0] += c.x; p[1] += c.y; p[2] += c.z;
 }
 
 // environment map on a miss (pathtrace.cu:303-311): img[pixel] += processNAN(color * env(sphere2Plane(direction)))
@@ -1001,6 +1091,273 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_shade_trace — the default render kernel (round 3): SHADE bounce d-1 and TRACE bounce d in one launch.
+//
+// The staged pipeline ran two full-width kernels per bounce (k_intersect, k_shade_binned).  With three iterations in flight the
+// machine spent a third of its time between kernels: rocprofv3 shows an average of 1.9 kernels in flight on three streams, every
+// kernel boundary is a drain, a dispatch and a ramp (and a cache write-back between the XCDs).  A surviving path's next ray is in
+// registers at the end of shading — so the block that shaded it finds its closest hit at once, block-cooperatively like k_intersect
+// (analytic_closest_lds), and writes path state AND hit record together.  One iteration = 1 + traceDepth launches instead of
+// 1 + 2 x traceDepth (+ traceDepth one-block k_segments launches with one iteration at a time).
+//
+// What makes this possible without any inter-block communication inside the launch:
+//   * survivors stay in their block's window (segmented streams, as before), and the hit record of a survivor is stored at the
+//     SAME physical slot as its path state (two hit buffers ping-pong with the two path buffers);
+//   * the compacted slot of a hit path — the reference's RNG key (pathtrace.cu:458,532) — is
+//         hit_pref[window] + (rank of the path among the hits of its window),
+//     the rank written next to the hit record by the block that traced it (`hr`: >= 0 rank, -1 miss, -2 empty slot), hit_pref by
+//     the last block of the launch (segments_tail) together with the window prefix.  The O(blocks) re-summation of the per-block
+//     hit counts at the head of k_shade_binned is gone;
+//   * LDS: the shading phase's tables (materials, counting-sort permutation, slots) and the tracing phase's pair list share 8 KB,
+//     so the kernel keeps k_intersect's 24.6 KB = six blocks per CU.
+// GEN: the first launch of an iteration generates the camera rays (generateRayFromCamera, pathtrace.cu:135-163) instead of shading.
+// SPLIT (scenes with triangles): the trace phase is the analytic part + the root-box test; k_list / k_traverse_wide / k_finalize
+// follow on the survivors' physical slots and k_finalize writes `hr` (a triangle hit changes the ranks).
+// Results are unchanged: same paths, same keys, same order of additions into every pixel.
+// ------------------------------------------------------------------------------------------------------------------
+struct TraceIO {
+    // the bounce being shaded (unused with GEN): paths, their hit records and hit ranks at PHYSICAL slots, the window tables
+    PtkPaths cur; PtkHits hcur; const int* hr_cur;
+    const int* pref; const int* first; const int* hit_pref;
+    // the bounce being traced: survivors (or fresh camera rays), their hit records and ranks
+    PtkPaths nxt; PtkHits hnxt; int* hr_nxt;
+    int* agg_s; int* agg_h;              // per-window survivor / hit counts of this launch
+    int* valid_nxt;                      // SPLIT: 0 / 1 / -2 per slot for k_traverse / k_finalize
+    int* heavy_flag; int* heavy_agg;     // SPLIT: rays that enter the BVH root box
+};
+struct SegTail2 { int* done; int* pref; int* first; int* hit_pref; int* count_out; int* iter_advance; int iter_stride; unsigned long long* ray_total; };
+struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix; };
+
+// end of a k_shade_trace block: publish the window's survivor and hit counts; the last block of the launch builds the tables
+template <int NT>
+__device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, int survivors, int hits, int* __restrict__ agg_s, int* __restrict__ agg_h) {
+    __shared__ int s_last;
+    const int nb = (n + NT - 1) / NT, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(agg_s + b, survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (agg_h) __hip_atomic_store(agg_h + b, hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int grp = b / PTK_SEG_GROUP;
+        const int gsize = min(PTK_SEG_GROUP, nb - grp * PTK_SEG_GROUP);
+        int last = 0;
+        if (__hip_atomic_fetch_add(T.done + 32 * (grp + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1)
+            last = __hip_atomic_fetch_add(T.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int k = threadIdx.x; k <= ng; k += NT) __hip_atomic_store(T.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (T.hit_pref && agg_h) (void)prefix_block<NT, true>(n > 0 ? nb : 0, agg_h, T.hit_pref);
+    segments_block<NT, true>(n, agg_s, T.pref, T.first, T.count_out, T.iter_advance, T.iter_stride);
+    if (threadIdx.x == 0 && T.ray_total) atomicAdd(T.ray_total, (unsigned long long)*T.count_out);     // rays of the bounce just traced
+}
+
+// dense index -> (physical slot, window) of the segmented stream (gather_source + the window, whose hit prefix the caller needs)
+__device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, const int* __restrict__ first, const int* __restrict__ hit_pref,
+                                               int b, int i, int n, int& hit_base) {
+    const int w0 = first[b];                                      // block-uniform: scalar loads
+    const int p0 = pref[w0], p1 = pref[w0 + 1], p2 = pref[w0 + 2], p3 = pref[w0 + 3], p4 = pref[w0 + 4];
+    const int h0 = hit_pref[w0], h1 = hit_pref[w0 + 1], h2 = hit_pref[w0 + 2], h3 = hit_pref[w0 + 3], h4 = hit_pref[w0 + 4];
+    hit_base = 0;
+    if (i >= n) return 0;
+    int k = (i >= p1) + (i >= p2) + (i >= p3) + (i >= p4);
+    int base = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : (k == 3 ? p3 : p4)));
+    hit_base = k == 0 ? h0 : (k == 1 ? h1 : (k == 2 ? h2 : (k == 3 ? h3 : h4)));
+    if (k == 4) {                                                 // many sparse windows in a row: walk on (pref ends with `total` > i)
+        int nxt = pref[w0 + k + 1];
+        while (i >= nxt) { base = nxt; ++k; nxt = pref[w0 + k + 1]; }
+        hit_base = hit_pref[w0 + k];
+    }
+    return (w0 + k) * PTK_BLOCK + (i - base);
+}
+
+template <int MODE, bool GEN, bool SPLIT>
+__global__ void __launch_bounds__(PTK_BLOCK, 4) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+                                                             const int* __restrict__ d_n, TraceIO io, float* __restrict__ img_base, unsigned plane_stride,
+                                                             int spp, int slot_bias, SegTail2 tail) {
+    constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6;
+    // 8 KB shared by the two phases: shading = materials (5120 B) + permutation / slot / source tables (3 x 1 KB); tracing = pair list
+    __shared__ __attribute__((aligned(16))) unsigned char s_over[8192];
+    __shared__ float4 s_ray[2 * NT];
+    __shared__ float2 s_res[3 * NT];
+    __shared__ unsigned long long s_best[NT];
+    __shared__ int s_cnt[NW][NKEY];
+    __shared__ int s_red[NW];
+    __shared__ int s_tcnt[NW];
+    DevMaterial* s_mats = reinterpret_cast<DevMaterial*>(s_over);
+    int* s_perm = reinterpret_cast<int*>(s_over + PTK_LDS_MATS * sizeof(DevMaterial));
+    int* s_slot = s_perm + NT;
+    int* s_src = s_slot + NT;
+    static_assert(PTK_LDS_MATS * sizeof(DevMaterial) + 3 * NT * sizeof(int) <= 8192 && NT * 16 * sizeof(unsigned short) <= 8192, "phase overlay");
+    const TraceLds L = {s_ray, s_res, s_best, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
+
+    const int step = iter_ptr ? *iter_ptr : iter_arg;
+    const int n = GEN ? gen.n_pix * spp : (d_n ? *d_n : n_arg);      // paths of the bounce being shaded (GEN: rays to generate)
+    const Film img = {img_base, plane_stride};
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (b * NT >= n) {
+        // no live path at all: nobody runs the tail, block 0 does the (empty) bookkeeping of the bounce
+        if (n <= 0 && b == 0) {
+            if (tail.hit_pref && tid < 8) tail.hit_pref[tid] = 0;
+            segments_block<NT, false>(0, io.agg_s, tail.pref, tail.first, tail.count_out, tail.iter_advance, tail.iter_stride);
+        }
+        return;
+    }
+    const GeomStage gs = stage_geoms(S);                           // the trace phase always needs the primitives; MIS / DIRECT shading too
+    const int i = b * NT + tid;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int alive = 0, my_rank = -1;           // this thread's shaded path survives, at rank my_rank of the window
+    int total = 0;                         // survivors of the block
+    if (GEN) {
+        // ---- generateRayFromCamera: path i -> pixel through the tile partition, sample s of the batch (see k_generate)
+        total = min(NT, n - b * NT);
+        if (i < n) {
+            alive = 1; my_rank = tid;
+            const int n_pix = gen.n_pix;
+            const int sidx = i / n_pix, jp = i - sidx * n_pix;
+            const int iter = (step - 1) * spp + sidx + 1;
+            const int lr = jp / gen.cam.W, x = jp - lr * gen.cam.W;
+            const int y = ((lr / gen.tile_rows) * gen.n_parts + gen.part) * gen.tile_rows + (lr % gen.tile_rows);
+            Rng rng = make_rng(x, y, iter);                       // argument order of pathtrace.cu:148: (iter:=x, index:=y, depth:=iter)
+            const f2 r = sample2D(rng);
+            const float fx = static_cast<float>(static_cast<float>(x) + ((double)r.x - 0.5) - gen.cam.W * 0.5f);
+            const float fy = static_cast<float>(static_cast<float>(y) + ((double)r.y - 0.5) - gen.cam.H * 0.5f);
+            const f3 d = normalize(gen.cam.view - gen.cam.right * gen.cam.plx * fx - gen.cam.up * gen.cam.ply * fy);
+            st4(io.nxt.o_pix, i, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, __int_as_float((sidx << 24) | (x + y * gen.cam.W))));
+            st4(io.nxt.d_bnc, i, make_float4(d.x, d.y, d.z, __int_as_float(gen.trace_depth)));
+            st4(io.nxt.col_pdf, i, make_float4(1.f, 1.f, 1.f, -1.f));
+            s_ray[2 * tid] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
+            s_ray[2 * tid + 1] = make_float4(d.x, d.y, d.z, 0.f);
+        }
+    } else {
+        // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
+        const int iter = (step - 1) * spp + 1;
+        const MatTable mt = stage_materials<NT>(S, s_mats);
+        int hit_base = 0;
+        const int src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, hit_base);      // 0 for i >= n
+        const int hr = (i < n) ? io.hr_cur[src_mine] : -1;
+        const int flag = hr >= 0;
+        s_src[tid] = src_mine;
+        const int mat_word = (i < n) ? __float_as_int(io.hcur.p_mat[4 * (size_t)src_mine + 3]) : 0;      // stale for a miss: unused then
+        int key = NKEY - 1;
+        if (flag) key = fetch_material_type(S, mt, mat_word);
+        unsigned long long bal[NKEY];
+#pragma unroll
+        for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
+        if (lane < NKEY) s_cnt[wid][lane] = __popcll(bal[lane]);
+        __syncthreads();
+        int rank = 0, n_active = 0;
+#pragma unroll
+        for (int k = 0; k < NKEY; ++k) {
+            int before_waves = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const int c = s_cnt[w][k]; before_waves += (w < wid) ? c : 0; tot += c; }
+            if (k < NKEY - 1) n_active += tot;
+            if (key == k) rank += before_waves + __popcll(bal[k] & lt);
+            else if (key > k) rank += tot;
+        }
+        s_perm[rank] = tid;
+        s_slot[tid] = hit_base + hr + slot_bias;
+        __syncthreads();
+        int src = -1;
+        PathRegs p;
+        p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
+        if (tid < n_active) {
+            src = s_perm[tid];
+            const int slot = s_slot[src];
+            const int ps = s_src[src];
+            const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps);
+            const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(io.hcur.uv_ids, ps);
+            const float4 o4 = ld4(io.cur.o_pix, ps), d4 = ld4(io.cur.d_bnc, ps), c4 = ld4(io.cur.col_pdf, ps);
+            Hit h;
+            h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+            h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
+            p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+            p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+            p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+            alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
+        }
+        __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
+        s_slot[tid] = 0;
+        __syncthreads();
+        if (src >= 0) s_slot[src] = alive;
+        __syncthreads();
+        const int alive_here = s_slot[tid];
+        const unsigned long long ab = __ballot(alive_here != 0);
+        if (lane == 0) s_red[wid] = __popcll(ab);
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = s_red[w]; before += (w < wid) ? c : 0; total += c; }
+        s_perm[tid] = before + __popcll(ab & lt);            // survivor rank of ORIGINAL position tid
+        __syncthreads();
+        if (alive) {
+            my_rank = s_perm[src];
+            const int s2 = b * NT + my_rank;
+            st4(io.nxt.o_pix, s2, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+            st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+            st4(io.nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+            s_ray[2 * my_rank] = make_float4(p.o.x, p.o.y, p.o.z, 0.f);          // hand the new ray to the thread that traces it
+            s_ray[2 * my_rank + 1] = make_float4(p.d.x, p.d.y, p.d.z, 0.f);
+        }
+    }
+    __syncthreads();                           // shading tables are dead, s_ray is complete: the pair list may overwrite s_over
+    // ---- trace phase: thread t < total traces survivor t of the window (computeIntersections, pathtrace.cu:169-346)
+    int hits = 0;
+    if (total > 0) {                           // block-uniform
+        const bool active = tid < total;
+        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+        if (active) { const float4 o4 = s_ray[2 * tid], d4 = s_ray[2 * tid + 1]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z); }
+        Analytic a;
+        if (gs.on) analytic_closest_lds<NT, true>(S, gs, L, active, ro, rd, a);
+        else { a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0); if (active) analytic_closest(S, gs, ro, rd, a); }
+        int flag = 0;
+        bool heavy = false;
+        const int slot = b * NT + tid;
+        if (active) {
+            Hit h;
+            flag = a.geom >= 0;
+            if (flag) { if (gs.on) analytic_record_staged(gs.xf, a, h); else analytic_record(S, a, h); }
+            if (SPLIT) {                       // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
+                const DevNode root = S.nodes[(size_t)mtbvh_dir(rd) * S.bvh_size];
+                float tEnter;
+                heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
+            }
+            if (flag) {
+                st4(io.hnxt.t_n, slot, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+                st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+                if (!S.slim_hits) st4(io.hnxt.uv_ids, slot, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+            } else {
+                st4(io.hnxt.t_n, slot, make_float4(-1.f, 0.f, 0.f, 0.f));
+            }
+        }
+        const unsigned long long hb = __ballot(flag != 0);
+        if (lane == 0) s_red[wid] = __popcll(hb);
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = s_red[w]; before += (w < wid) ? c : 0; hits += c; }
+        if (SPLIT) {
+            io.valid_nxt[slot] = active ? flag : -2;
+            io.heavy_flag[slot] = heavy ? 1 : 0;
+            const unsigned long long vb = __ballot(heavy);
+            __syncthreads();
+            if (lane == 0) s_red[wid] = __popcll(vb);
+            __syncthreads();
+            if (tid == 0) { int t = 0; for (int w = 0; w < NW; ++w) t += s_red[w]; io.heavy_agg[b] = t; }
+        } else {
+            io.hr_nxt[slot] = active ? (flag ? before + __popcll(hb & lt) : -1) : -2;
+        }
+    } else if (SPLIT) {
+        io.valid_nxt[b * NT + tid] = -2; io.heavy_flag[b * NT + tid] = 0;
+        if (tid == 0) io.heavy_agg[b] = 0;
+    } else {
+        io.hr_nxt[b * NT + tid] = -2;
+    }
+    segments_tail2<NT>(tail, n, b, total, hits, io.agg_s, SPLIT ? nullptr : io.agg_h);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // compact_rays, pathtrace.cu:614-631: k_count (per-block aggregates) + k_scatter (stable scatter, device count out)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PTK_BLOCK) k_count(int n_arg, const int* __restrict__ d_n, const int* __restrict__ valid, int* __restrict__ agg) {
@@ -1243,6 +1600,8 @@ struct TailArgs {
     float* img; unsigned plane_stride; int spp, slot_bias;
     unsigned long long* ray_total;
     int* iter_advance; int iter_stride;
+    // fused pipeline: bounce depth0 has been traced already (k_shade_trace); its hit records / ranks sit at the paths' physical slots
+    PtkHits hits0; const int* hr0; int have_hits;
 };
 
 template <int MODE>
@@ -1277,8 +1636,18 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
                 p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
                 p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
                 p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-                flag = closest_hit<false>(S, gs, p.o, p.d, h, nv, nt);
-                if (!flag && S.env_tex >= 0) add_radiance(img, p.pix, nan_to_zero(p.col * env_radiance(S, p.d)));   // pathtrace.cu:303-311
+                if (A.have_hits && depth == A.depth0) {             // traced by the last full-width launch (ENV radiance of its misses added there)
+                    flag = A.hr0[src] >= 0;
+                    if (flag) {
+                        const float4 h0 = ld4(A.hits0.t_n, src), h1 = ld4(A.hits0.p_mat, src);
+                        const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(A.hits0.uv_ids, src);
+                        h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+                        h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
+                    }
+                } else {
+                    flag = closest_hit<false>(S, gs, p.o, p.d, h, nv, nt);
+                    if (!flag && S.env_tex >= 0) add_radiance(img, p.pix, nan_to_zero(p.col * env_radiance(S, p.d)));   // pathtrace.cu:303-311
+                }
             }
             int total;
             const int local = block_excl_prefix_n<NT>(flag, total);
@@ -1295,7 +1664,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
         }
         if (threadIdx.x == 0) {
             A.counts[depth + 1] = survivors;
-            if (A.ray_total) atomicAdd(A.ray_total, (unsigned long long)n);
+            if (A.ray_total && !(A.have_hits && depth == A.depth0)) atomicAdd(A.ray_total, (unsigned long long)n);     // (counted by the launch that traced it)
         }
         __syncthreads();                                         // this bounce's stores are visible to the whole workgroup before the next bounce reads them
         const PtkPaths t = cur; cur = nxt; nxt = t;
@@ -1529,7 +1898,7 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg, G);
     else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg, G);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue);
+    k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
@@ -1613,10 +1982,90 @@ int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int c
     default: return PTK_E_BADARG;
     }
 }
+// fused pipeline: one launch shades bounce dt - 1 (paths / hits / ranks of `cur`) — or, gen, generates the camera rays — and traces
+// bounce dt into `nxt`.  Scenes with triangles continue with the work-list BVH stage on the survivors' physical slots.
+template <int MODE, bool GEN>
+static int launch_shade_trace_t(const SceneView& S, bool split, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
+                                const TraceIO& io, float* img, unsigned plane_stride, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
+    const int g = grid_for(capacity);
+    if (split) k_shade_trace<MODE, GEN, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    else k_shade_trace<MODE, GEN, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    return launch_rc();
+}
+int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
+                       int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
+                       bool last, void (*mark)(int, bool)) {
+    const int g = grid_for(capacity);
+    if (g == 0) return 0;
+    if (!ws.seg_pref || !ws.seg_first || !ws.hit_pref || !ws.agg_h || !ws.agg_b || !ws.seg_done || !ws.tr_valid || !ws.tr_heavy) return PTK_E_BADARG;
+    SceneView S = S_in;
+    S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
+    const bool split = S.n_tris > 0 && ws.queue && ws.list;
+    GenArgs G;
+    G.cam.W = cam.resolution.x; G.cam.H = cam.resolution.y;
+    G.cam.pos = mk3(cam.position.x, cam.position.y, cam.position.z);
+    G.cam.view = mk3(cam.view.x, cam.view.y, cam.view.z);
+    G.cam.up = mk3(cam.up.x, cam.up.y, cam.up.z);
+    G.cam.right = mk3(cam.right.x, cam.right.y, cam.right.z);
+    G.cam.plx = cam.pixelLength.x; G.cam.ply = cam.pixelLength.y;
+    G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix;
+    TraceIO io;
+    io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr;
+    io.pref = ws.seg_pref; io.first = ws.seg_first; io.hit_pref = ws.hit_pref;
+    io.nxt = nxt.paths; io.hnxt = nxt.hits; io.hr_nxt = nxt.hr;
+    io.agg_s = ws.agg_b; io.agg_h = ws.agg_h;
+    io.valid_nxt = ws.tr_valid; io.heavy_flag = ws.tr_heavy; io.heavy_agg = ws.agg_a;
+    // the launch that shades bounce dt - 1 reads counts[dt - 1]; its last block writes counts[dt] = the rays it traced
+    const int* d_n = gen ? nullptr : ws.counts + (dt - 1);
+    const SegTail2 tail = {ws.seg_done, ws.seg_pref, ws.seg_first, split ? nullptr : ws.hit_pref, ws.counts + dt, last ? ws.iter_dev : nullptr, ws.iter_stride, ws.ray_total};
+    const int depth = dt - 1;           // RNG key depth of the bounce being shaded
+    mark(gen ? 0 : 2, true);
+    int rc;
+    if (gen) {
+        switch (mode) {                 // (the mode only matters for the hit-record layout the next launch expects: same kernel body)
+        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        }
+    } else {
+        switch (mode) {
+        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        default: rc = PTK_E_BADARG;
+        }
+    }
+    mark(gen ? 0 : 2, false);
+    if (rc) return rc;
+    // the traced stream lives in the windows [0, ceil(n_shaded / 256)): the follow-up kernels take the shaded bounce's count as their bound
+    const int n_bound = gen ? n_pix * ws.spp : capacity;
+    if (split) {
+        mark(1, true);
+        k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1);
+        if ((rc = launch_rc())) { mark(1, false); return rc; }
+        const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
+        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        else if (wide) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        if ((rc = launch_rc())) { mark(1, false); return rc; }
+        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h);
+        if ((rc = launch_rc())) { mark(1, false); return rc; }
+        k_hit_prefix<<<1, 1024, 0, st>>>(n_bound, d_n, ws.agg_h, ws.hit_pref);
+        mark(1, false);
+        if ((rc = launch_rc())) return rc;
+    }
+    if (S.env_tex >= 0) {
+        k_env_miss2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.paths, nxt.hr, img, ws.plane_stride);
+        if ((rc = launch_rc())) return rc;
+    }
+    return 0;
+}
 // all bounces from `depth0` on in one single-workgroup launch (k_tail); cur = the stream entering bounce depth0
-int launch_tail(const SceneView& S, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
-                const Workspace& ws, hipStream_t st) {
+int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
+                const Workspace& ws, hipStream_t st, const PtkHits* hits0, const int* hr0) {
+    SceneView S = S_in;
     TailArgs A;
+    A.have_hits = hits0 != nullptr ? 1 : 0;
+    A.hits0 = hits0 ? *hits0 : PtkHits{nullptr, nullptr, nullptr}; A.hr0 = hr0;
+    if (hits0) S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;      // as the launch that wrote them
     A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth0 = depth0; A.trace_depth = trace_depth;
     A.counts = ws.counts; A.cur = cur; A.nxt = nxt;
     const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;

@@ -183,14 +183,15 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("pipeline", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
     """ptk_set_pipeline variants (1 = staged kernels with the BVH walked inside the intersect kernel, 2 = the same with wave-uniform
     loops over every analytic primitive instead of the staged candidate loops, 3 = the fused bounce kernel with chained scans,
     4 = staged intersect + shading that compacts its survivors through one chained scan, 5 = default pipeline with the work-list
     rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree with four lanes per ray, 7 / 8 = default pipeline with the
-    window bookkeeping in a separate k_segments launch / in the shading kernel's last block, 9 = every bounce at full width (no k_tail))
-    produce exactly the oracle's results."""
+    window bookkeeping in a separate k_segments launch / in the shading kernel's last block, 9 = every bounce at full width (no k_tail),
+    10 = the default, explicitly: one fused shade + trace launch per bounce; 7 / 8 are the staged kernels that were the default until
+    round 3) produce exactly the oracle's results."""
     for name, res, depth, mode in (("bunny_cornell.txt", (128, 128), 5, "MIS"), ("obj_test.txt", (64, 64), 4, "BSDF"), ("cornell.txt", (96, 96), 4, "BSDF")):
         m = MODES[mode]
         s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
