@@ -432,21 +432,40 @@ PTK_DI GeomXf load_xf(const float* xf, int i, int diag) {
 // boxIntersectionTest, intersections.h:48-90.  Returns world-space distance or -1.
 // The normal is NOT computed here: `ns` receives the object-space vector n with N = normalize(invTranspose * n), so the
 // caller evaluates it once for the primitive that wins (the reference evaluates it for every candidate and discards it).
-// the six slab distances of the unit cube, t1 = (-0.5 - o) / d and t2 = (+0.5 - o) / d per axis (intersections.h:59-61): six correctly
-// rounded quotients over three denominators — x and y in packed steps, the two z planes as one pair over d.z
-PTK_DI void box_slabs(f3 o, f3 d, f3& t1, f3& t2) {
+// The exact tests in two forms.  FAST (device only): every divide / sqrt / 1/sqrt through the *_steps sequences with NO branch, the
+// range conditions of all of them ANDed into `ok` (a handful of compares; a guarded helper per operation costs an exec-mask
+// save / restore and a branch each — measured 4-6 % of the headline).  Conditions that follow from earlier ones are not tested again:
+// a vector that was just normalised has |v|^2 within a few ulps of 1, so the second normalize of getPointOnRay
+// (intersections.h:27-29) is always in range when the first was.  The caller recomputes the whole test in the plain form when
+// `ok` comes back false — zero / denormal / huge / NaN operands, a slab numerator that is exactly 0, a grazing sphere radicand.
+template <bool FAST> PTK_DI float t_inv_sqrt(float x, bool& ok, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) { ok = ok && ex_in(x, lo, hi); const float s = sqrt_steps(x); return inv_steps(s, rcp_refined(s)); }
+#endif
+    return 1.0f / sqrtf(x);
+}
+template <bool FAST> PTK_DI float t_inv_sqrt_unit(float x) {       // x = |v|^2 of a vector normalised by a FAST step: in range by construction
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) { const float s = sqrt_steps(x); return inv_steps(s, rcp_refined(s)); }
+#endif
+    return 1.0f / sqrtf(x);
+}
+template <bool FAST> PTK_DI float t_sqrt(float x, bool& ok, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) { ok = ok && ex_in(x, lo, hi); return sqrt_steps(x); }
+#endif
+    return sqrtf(x);
+}
+template <bool FAST> PTK_DI void t_box_slabs(f3 o, f3 d, f3& t1, f3& t2, bool& ok) {
     const f3 n1 = mk3(-0.5f, -0.5f, -0.5f) - o, n2 = mk3(0.5f, 0.5f, 0.5f) - o;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Range test, every compare false for a NaN.  Numerators: |o| <= 2^39 bounds them above; below, -0.5 - o and 0.5 - o are exact
-    // next to 0 (Sterbenz), so a numerator is either 0 — when |o| == 0.5 — or at least 2^-25.
-    const float ox = __builtin_fabsf(o.x), oy = __builtin_fabsf(o.y), oz = __builtin_fabsf(o.z);
-#ifdef PTK_EX_NOFALLBACK
-    const bool num_ok = true; (void)ox; (void)oy; (void)oz;
-#else
-    const bool num_ok = (ox <= 0.5f * PTK_EX_HI && ox != 0.5f) && (oy <= 0.5f * PTK_EX_HI && oy != 0.5f) && (oz <= 0.5f * PTK_EX_HI && oz != 0.5f);
-#endif
-    const bool den_ok = ex_in(__builtin_fabsf(d.x), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d.y), PTK_EX_LO, PTK_EX_HI) && ex_in(__builtin_fabsf(d.z), PTK_EX_LO, PTK_EX_HI);
-    if (num_ok && den_ok) {
+    if (FAST) {
+        // numerators: |o| <= 2^39 bounds them above; below, -0.5 - o and 0.5 - o are exact next to 0 (Sterbenz), so a numerator is 0 —
+        // when |o| == 0.5 — or at least 2^-25.  Denominators: components of a vector normalised by a FAST step (<= 1 + a few ulps): only
+        // the lower bound needs a test.  Every compare is false for a NaN.
+        const float ox = __builtin_fabsf(o.x), oy = __builtin_fabsf(o.y), oz = __builtin_fabsf(o.z);
+        ok = ok && (ox <= 0.5f * PTK_EX_HI && ox != 0.5f) && (oy <= 0.5f * PTK_EX_HI && oy != 0.5f) && (oz <= 0.5f * PTK_EX_HI && oz != 0.5f) &&
+             __builtin_fabsf(d.x) >= PTK_EX_LO && __builtin_fabsf(d.y) >= PTK_EX_LO && __builtin_fabsf(d.z) >= PTK_EX_LO;
         const ptk_v2f dxy = xy_of(d), yxy = rcp_refined2(dxy);
         const float yz = rcp_refined(d.z);
         const ptk_v2f a = div_steps2(xy_of(n1), dxy, yxy), b = div_steps2(xy_of(n2), dxy, yxy);
@@ -458,14 +477,15 @@ PTK_DI void box_slabs(f3 o, f3 d, f3& t1, f3& t2) {
     t1 = mk3(n1.x / d.x, n1.y / d.y, n1.z / d.z); t2 = mk3(n2.x / d.x, n2.y / d.y, n2.z / d.z);
 }
 
-template <class G>
-PTK_DI float box_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
+template <bool FAST, class G>
+PTK_DI float box_test_impl(const G& g, f3 ro, f3 rd, f3& P, f3& ns, bool& ok) {
     f3 qo = xform_point_d(g.inv, ro, g.diag);
-    f3 qd = normalize(xform_dir_d(g.inv, rd, g.diag));
+    const f3 qv = xform_dir_d(g.inv, rd, g.diag);
+    f3 qd = qv * t_inv_sqrt<FAST>(dot(qv, qv), ok, PTK_EX_LO2, PTK_EX_HI2);
     float tmin = -1e38f, tmax = 1e38f;
     int amin = 0, amax = 0; float smin = 0.f, smax_ = 0.f;     // normal = axis * sign (zero-initialised tmin_n/tmax_n)
     f3 s1, s2;
-    box_slabs(qo, qd, s1, s2);
+    t_box_slabs<FAST>(qo, qd, s1, s2, ok);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float t1 = comp(s1, a);
@@ -478,32 +498,70 @@ PTK_DI float box_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
     if (tmax >= tmin && tmax > 0) {
         if (tmin <= 0) { tmin = tmax; amin = amax; smin = smax_; }
         ns = mk3(amin == 0 ? smin : 0.f, amin == 1 ? smin : 0.f, amin == 2 ? smin : 0.f);
-        f3 p = qo + (tmin - .0001f) * normalize(qd);                       // getPointOnRay, intersections.h:27-29
+        f3 p = qo + (tmin - .0001f) * (qd * t_inv_sqrt_unit<FAST>(dot(qd, qd)));      // getPointOnRay, intersections.h:27-29: normalize(qd) again
         P = xform_point_d(g.fwd, p, g.diag);
-        return length(ro - P);
+        const f3 dv = ro - P;
+        return t_sqrt<FAST>(dot(dv, dv), ok, PTK_EX_LO2, PTK_EX_HI2);
     }
     return -1.f;
 }
+// boxIntersectionTest, intersections.h:48-90.  Returns world-space distance or -1.
+// The normal is NOT computed here: `ns` receives the object-space vector n with N = normalize(invTranspose * n), so the
+// caller evaluates it once for the primitive that wins (the reference evaluates it for every candidate and discards it).
+template <class G>
+PTK_DI float box_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PTK_EX_PLAIN)
+    bool ok = true;
+    f3 Pf = mk3(0, 0, 0), nf = mk3(0, 0, 0);
+    const float t = box_test_impl<true>(g, ro, rd, Pf, nf, ok);
+#ifndef PTK_EX_NOFALLBACK
+    if (__builtin_expect(!ok, 0)) { bool dummy = true; return box_test_impl<false>(g, ro, rd, P, ns, dummy); }
+#endif
+    if (t >= 0.f) { P = Pf; ns = nf; }
+    return t;
+#else
+    bool dummy = true;
+    return box_test_impl<false>(g, ro, rd, P, ns, dummy);
+#endif
+}
 
 // sphereIntersectionTest, intersections.h:102-144 (normal deferred like box_test: ns = object-space hit point)
-template <class G>
-PTK_DI float sphere_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
+template <bool FAST, class G>
+PTK_DI float sphere_test_impl(const G& g, f3 ro, f3 rd, f3& P, f3& ns, bool& ok) {
     f3 o = xform_point_d(g.inv, ro, g.diag);
-    f3 d = normalize(xform_dir_d(g.inv, rd, g.diag));
+    const f3 dv0 = xform_dir_d(g.inv, rd, g.diag);
+    f3 d = dv0 * t_inv_sqrt<FAST>(dot(dv0, dv0), ok, PTK_EX_LO2, PTK_EX_HI2);
     float vd = dot(o, d);
     float radicand = vd * vd - (dot(o, o) - 0.25f);
     if (radicand < 0) return -1.f;
-    float sq = sqrt_exact(radicand);
+    float sq = t_sqrt<FAST>(radicand, ok, PTK_EX_LO2, PTK_EX_HI2);
     float first = -vd;
     float t1 = first + sq, t2 = first - sq;
     float t;
     if (t1 < 0 && t2 < 0) return -1.f;
     else if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
     else t = (t1 < t2) ? t2 : t1;
-    f3 obj = o + (t - .0001f) * normalize(d);
+    f3 obj = o + (t - .0001f) * (d * t_inv_sqrt_unit<FAST>(dot(d, d)));
     P = xform_point_d(g.fwd, obj, g.diag);
     ns = obj;
-    return length(ro - P);
+    const f3 dv = ro - P;
+    return t_sqrt<FAST>(dot(dv, dv), ok, PTK_EX_LO2, PTK_EX_HI2);
+}
+template <class G>
+PTK_DI float sphere_test(const G& g, f3 ro, f3 rd, f3& P, f3& ns) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PTK_EX_PLAIN)
+    bool ok = true;
+    f3 Pf = mk3(0, 0, 0), nf = mk3(0, 0, 0);
+    const float t = sphere_test_impl<true>(g, ro, rd, Pf, nf, ok);
+#ifndef PTK_EX_NOFALLBACK
+    if (__builtin_expect(!ok, 0)) { bool dummy = true; return sphere_test_impl<false>(g, ro, rd, P, ns, dummy); }
+#endif
+    if (t >= 0.f) { P = Pf; ns = nf; }
+    return t;
+#else
+    bool dummy = true;
+    return sphere_test_impl<false>(g, ro, rd, P, ns, dummy);
+#endif
 }
 // the deferred normal of an analytic primitive: normalize(invTranspose * ns)  (intersections.h:87, 138)
 PTK_DI f3 analytic_normal(const DevGeom& g, f3 ns) { return normalize(xform_nrm_d(g.invT, ns, g.diag)); }

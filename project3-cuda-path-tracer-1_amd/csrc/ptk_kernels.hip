@@ -1172,7 +1172,7 @@ __device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, con
 }
 
 template <int MODE, bool GEN, bool SPLIT>
-__global__ void __launch_bounds__(PTK_BLOCK, 4) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : 6)) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
                                                              const int* __restrict__ d_n, TraceIO io, float* __restrict__ img_base, unsigned plane_stride,
                                                              int spp, int slot_bias, SegTail2 tail) {
     constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6;
@@ -1708,7 +1708,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_sum_planes(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// TEST-ONLY: the exact fast paths of ptk_device.hpp (div_exact / inv_exact / sqrt_exact / inv_sqrt_exact / div3_exact / box_slabs,
+// TEST-ONLY: the exact fast paths of ptk_device.hpp (div_exact / inv_exact / sqrt_exact / inv_sqrt_exact / div3_exact / box_test / sphere_test,
 // the packed dot / normalize / xform_*) against the plain IEEE forms (`/`, sqrtf, scalar arithmetic in glm's order), bit for bit,
 // on pseudo-random operand sets: any bit pattern, moderate magnitudes, the edges of the fast-path ranges (2^-40, 2^40, 2^-80, 2^80,
 // 2^-96), slab numerators next to zero.  bad[k] counts the mismatches of check k (NaN == NaN).  tests/test_gpu_exact_math.py.
@@ -1742,9 +1742,24 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_exact_check(unsigned long long n,
     m |= chk_same(inv_sqrt_exact(pa), 1.0f / sqrtf(pa)) ? 0u : 8u;
     { const f3 q = div3_exact(mk3(a, b, c), d);
       m |= (chk_same(q.x, a / d) && chk_same(q.y, b / d) && chk_same(q.z, c / d)) ? 0u : 16u; }
-    { f3 t1, t2; box_slabs(mk3(a, b, c), mk3(d, e, f), t1, t2);
-      const bool ok = chk_same(t1.x, (-0.5f - a) / d) && chk_same(t1.y, (-0.5f - b) / e) && chk_same(t1.z, (-0.5f - c) / f) &&
-                      chk_same(t2.x, (0.5f - a) / d) && chk_same(t2.y, (0.5f - b) / e) && chk_same(t2.z, (0.5f - c) / f);
+    { // the exact tests as the kernels call them (optimistic fast form + plain fallback) against the plain form alone, on a random
+      // transform (general and diagonal) and a ray made of the operand set: distance, hit point and deferred normal, bit for bit
+      struct { float inv[12], fwd[12]; int diag; } g;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { g.inv[k] = chk_operand(utilhash(h[7] + (uint32_t)k), (k % 5 == 0 || k == 3 || k == 7 || k == 11) ? 1 : (cls == 0 ? 0 : 1));
+                                     g.fwd[k] = chk_operand(utilhash(h[7] + 100u + (uint32_t)k), 1); }
+      bool ok = true;
+#pragma unroll
+      for (int dg = 0; dg < 2; ++dg) {
+          g.diag = dg;
+          const f3 ro = mk3(a, b, c), rd = mk3(d, e, f);
+          f3 P1 = mk3(0, 0, 0), n1 = mk3(0, 0, 0), P2 = mk3(0, 0, 0), n2 = mk3(0, 0, 0);
+          bool dummy = true;
+          const float t1 = box_test(g, ro, rd, P1, n1), t2 = box_test_impl<false>(g, ro, rd, P2, n2, dummy);
+          ok = ok && chk_same(t1, t2) && (!(t2 >= 0.f) || (chk_same(P1.x, P2.x) && chk_same(P1.y, P2.y) && chk_same(P1.z, P2.z) && chk_same(n1.x, n2.x) && chk_same(n1.y, n2.y) && chk_same(n1.z, n2.z)));
+          const float u1 = sphere_test(g, ro, rd, P1, n1), u2 = sphere_test_impl<false>(g, ro, rd, P2, n2, dummy);
+          ok = ok && chk_same(u1, u2) && (!(u2 >= 0.f) || (chk_same(P1.x, P2.x) && chk_same(P1.y, P2.y) && chk_same(P1.z, P2.z) && chk_same(n1.x, n2.x) && chk_same(n1.y, n2.y) && chk_same(n1.z, n2.z)));
+      }
       m |= ok ? 0u : 32u; }
     { const f3 v = mk3(a, b, c), nv = normalize(v);
       const float r = 1.0f / sqrtf(a * a + b * b + c * c);

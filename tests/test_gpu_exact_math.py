@@ -1,4 +1,4 @@
-"""The kernels' exact fast paths (csrc/ptk_device.hpp: div_exact, inv_exact, sqrt_exact, inv_sqrt_exact, div3_exact, box_slabs, and
+"""The kernels' exact fast paths (csrc/ptk_device.hpp: div_exact, inv_exact, sqrt_exact, inv_sqrt_exact, div3_exact, the optimistic box_test / sphere_test, and
 the packed dot / normalize / length / xform_*) return the SAME BITS as the plain IEEE forms the reference's arithmetic is restated in
 (`/`, sqrtf, scalar products and sums in glm's order).  Checked on the device itself — the helpers exist only there — over 2^28
 pseudo-random operand sets per seed: arbitrary bit patterns (NaN, inf, denormals, zeros), moderate magnitudes, the edges of the
@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CHECKS = ("div_exact", "inv_exact", "sqrt_exact", "inv_sqrt_exact", "div3_exact", "box_slabs", "dot/normalize/length", "xform_*")
+CHECKS = ("div_exact", "inv_exact", "sqrt_exact", "inv_sqrt_exact", "div3_exact", "box_test/sphere_test", "dot/normalize/length", "xform_*")
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
