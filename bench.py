@@ -139,8 +139,6 @@ def cpu_baseline(scene_path, res, depth, mode, seconds):
 def measure_kernels(ptk, scene, mode, pipeline, steps):
     """Untimed diagnostic pass on ONE stream (no overlap): per-kernel device time from HIP events on the render stream, plus
     BVH traversal statistics for scenes with triangles."""
-    if pipeline in (0, 10):
-        pipeline = 8            # the staged kernels: k_intersect on its own (SURVEY 8d's 76 B / ray figure is defined on it)
     r = ptk.Renderer(scene, mode, pipeline=pipeline, in_flight=1, graph=False)
     for it in (1, 2):
         r.iterate(it)
@@ -164,11 +162,14 @@ def measure_kernels(ptk, scene, mode, pipeline, steps):
     return prof, rays, counts, nodes, tris, rays_s
 
 
-PMC_FILE = "profiles/r2_pmc.json"
+ROUND = "r3"
+PMC_FILE = "profiles/%s_pmc.json" % ROUND
+BYTES_PER_PATH_BOUNCE = 224   # whole bounce (intersect 76 + 2 x 8 index-only compaction + shade 132) per path-bounce
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4      # wave-instructions / s: 1024 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz
 
 
 def pmc_record(scene_file):
-    """Committed rocprofv3 PMC passes of the intersect stage (profiles/r2_pmc.json says how they were taken: separate --pmc
+    """Committed rocprofv3 PMC passes of the intersect stage (profiles/r3_pmc.json says how they were taken: separate --pmc
     passes with --kernel-trace only; FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md).  PMC collection cannot run inside
     this process, so the numbers are read from the committed summary."""
     try:
@@ -178,16 +179,18 @@ def pmc_record(scene_file):
 
 
 def rocprof_avg_us(scene_file, kernel_substr):
-    """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of the single-stream configuration
-    (profiles/r2_<scene>_kernel_stats_inflight1.csv, produced by tools/refresh_profiles.sh with `bench.py --in-flight 1 --graph 0`)"""
+    """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summaries of the single-stream configuration
+    (profiles/r3_<scene>_kernel_stats_inflight1_p<pipeline>.csv, produced by tools/refresh_profiles.sh with `bench.py --in-flight 1
+    --graph 0 --pipeline 0 | 8`: the fused default and the staged kernels)"""
     import csv
-    try:
-        f = os.path.join(ROOT, "profiles", "r2_%s_kernel_stats_inflight1.csv" % (scene_file or "").replace(".txt", ""))
-        for row in csv.DictReader(open(f)):
-            if kernel_substr in row["Name"]:
-                return float(row["AverageNs"]) / 1e3
-    except Exception:
-        pass
+    for p in (0, 8):
+        try:
+            f = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats_inflight1_p%d.csv" % (ROUND, (scene_file or "").replace(".txt", ""), p))
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row["Name"]:
+                    return float(row["AverageNs"]) / 1e3
+        except Exception:
+            pass
     return None
 
 
@@ -205,15 +208,18 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
            "achieved_hbm_note": "PMC traffic / this run's average launch time: the rate the HBM really sees (node / triangle re-reads of a "
                                 "BVH scene are served by L2); `achieved` is the ALGORITHMIC rate at the reference's struct sizes (SURVEY 8d)"} if traffic else {}
     return {
-        "bound": "hbm", "kernel": "k_intersect" + (" + k_list + k_traverse_wide + k_finalize (the intersect stage)" if has_bvh else ""),
+        "bound": "valu" if not has_bvh else "valu+latency",
+        "bound_note": "priced against the HBM roofline as the contract asks, but NOT bound by it: PMC traffic ~= the algorithmic bytes and the kernel sits at "
+                      "~0.2 of 8 TB/s because it needs ~14 VALU instructions per byte; see roofline_valu and DESIGN.md section 5",
+        "kernel": "k_intersect (the staged pipeline 8's intersection kernel, the kernel SURVEY 8d's 76 B/ray is defined on)" + (" + k_list + k_traverse_wide + k_finalize (the intersect stage)" if has_bvh else ""),
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE, **hbm,
         "counters": (pmc or {}).get("counters"),
         **({"avg_launch_us_rocprof": round(rp_us, 2), "frac_rocprof": round(bytes_per_ray * rays_p / (steps * live_launches) / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
             "rocprof_note": "k_intersect's average duration in the committed rocprofv3 summary of the same single-stream configuration "
-                            "(profiles/r2_%s_kernel_stats_inflight1.csv); the live HIP-event figure above brackets every launch with two event "
-                            "records and so includes ~3 us of dispatch / event latency per launch" % (scene_file or "").replace(".txt", "")}
+                            "(profiles/%s_%s_kernel_stats_inflight1_p8.csv); the live HIP-event figure above brackets every launch with two event "
+                            "records and so includes ~3 us of dispatch / event latency per launch" % (ROUND, (scene_file or "").replace(".txt", ""))}
            if (rp_us and not has_bvh) else {}),
         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_p / (steps * live_launches)),
         "bytes_per_ray": round(bytes_per_ray, 2), "rays_per_launch": round(rays_p / (steps * live_launches), 1),
@@ -236,6 +242,42 @@ def self_launch(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
+    """The dominant kernel of the benchmarked pipeline: k_shade_trace (shade bounce d-1 + trace bounce d in one launch; its first
+    launch of an iteration generates the camera rays instead of shading).  Algorithmic bytes = SURVEY 8(d)'s whole-bounce figure,
+    224 B per path-bounce, x the rays the launches traced, / the device time of those launches (HIP events on the render stream)."""
+    ms = prof["shade"][0] + prof["generate"][0]
+    launches = prof["shade"][1] + prof["generate"][1]
+    if ms <= 0 or launches <= 0:
+        return None
+    achieved = rays_p * BYTES_PER_PATH_BOUNCE / (ms * 1e-3) / 1e9
+    avg_us = 1e3 * ms / launches
+    rp = rocprof_avg_us(scene_file, "k_shade_trace<0, false, false>") if (scene.width, scene.height) == (800, 800) else None
+    pm = ((pmc_record(scene_file) or {}).get("k_shade_trace") or {}) if (scene.width, scene.height) == (800, 800) else {}
+    return {"bound": "valu", "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": round(rays_p * BYTES_PER_PATH_BOUNCE / launches), "bytes_per_path_bounce": BYTES_PER_PATH_BOUNCE,
+            "rays_per_launch": round(rays_p / launches, 1), "avg_launch_us": round(avg_us, 2), "avg_launch_us_rocprof": round(rp, 2) if rp else None,
+            "counters": pm.get("counters"),
+            "note": "HIP events on the render stream, %d untimed iterations on one stream (launches of the sparse tail excluded); per-kernel ms/iter: %s" % (
+                steps, {k: round(v[0] / steps, 4) for k, v in prof.items()})}
+
+
+def roofline_valu(scene_file, roof):
+    """Vector-ALU issue roofline of the kernel `roof` describes: wave-instructions per second (committed PMC pass: SQ_INSTS_VALU per launch /
+    this run's average launch time) against 1024 SIMDs x 2.4 GHz / 4 cycles.  tools/diag/issue_cost.hip measured what an instruction
+    really costs on gfx950: v_fma / v_mul / v_add_f32 ~3.1 cycles per wave64, v_pk_* f32 ~4.7 (two results), compares / selects / integer
+    ~4.3, v_rcp / v_sqrt ~8.2 — so the instruction count is not proportional to issue time (profiles/r3_issue_cost.txt)."""
+    c = (roof or {}).get("counters") or {}
+    if not c.get("SQ_INSTS_VALU") or not roof.get("avg_launch_us"):
+        return None
+    rate = c["SQ_INSTS_VALU"] / (roof["avg_launch_us"] * 1e-6)
+    return {"achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
+            "insts_valu_per_launch": c["SQ_INSTS_VALU"], "packed_share_static": c.get("packed_share_static"), "kernel": roof.get("kernel"),
+            "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the vector ALUs are "
+                    "~0.8 busy (valu_busy_estimate).  Packed instructions counted once here; their static share of the kernel's VALU instructions is packed_share_static"}
 
 
 def main():
@@ -360,9 +402,16 @@ def main():
                          "whole-frame work fixed, per-rank launches shrink by N); iteration_sharded (weak / strong): K*IPS / K*IPS/N "
                          "whole-frame iterations per rank"}
     if rank == 0:
-        prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, a.pipeline, a.profile_steps)
+        fused = a.pipeline in (0, 10)
+        staged = 8 if fused else a.pipeline        # k_intersect on its own: the kernel SURVEY 8d's 76 B / ray figure is defined on
+        prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, staged, a.profile_steps)
         roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)
         extra = {}
+        if fused:
+            pf = measure_kernels(ptk, scene, mode, 10, a.profile_steps)
+            extra["roofline_dominant"] = roofline_fused(scene, pf[0], pf[1], a.profile_steps, a.scene)
+            extra["roofline_valu_dominant"] = roofline_valu(a.scene, extra["roofline_dominant"])
+        extra["roofline_valu"] = roofline_valu(a.scene, roofline)
         if N == 1 and not a.lean and a.bvh_scene and a.bvh_scene != a.scene:
             # the HBM-fraction target is only meaningful where the kernel streams BVH data: same measurement
             # on the BASELINE configs[2] timed scene (bunny_cornell.txt, 800x800 depth 8)
@@ -375,7 +424,7 @@ def main():
                 rb.iterate(i)
             bms = rb.timer_stop(); brays = rb.ray_total() - rb0
             rb.close()
-            pb = measure_kernels(ptk, bs, mode, a.pipeline, a.profile_steps)
+            pb = measure_kernels(ptk, bs, mode, staged, a.profile_steps)
             extra["roofline_bvh_scene"] = dict(roofline_of(bs, *pb, a.profile_steps, a.bvh_scene), workload=f"scenes/{a.bvh_scene} {bs.width}x{bs.height} depth {bs.trace_depth}",
                                                mrays_per_s=round(brays / bms / 1e3, 1))
         ref_order = None
@@ -428,7 +477,10 @@ def main():
                                                           + ", one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
                        "iterations_total": head["calls"] * (N if a.shard == "iterations" else 1) * spp,
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
-                       "pipeline": "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync"},
+                       "pipeline": ("one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d (segmented streams, physical-slot hit records, window hit "
+                                    "prefixes); device-resident counts, no host sync") if a.pipeline in (0, 10) else
+                                   "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync",
+                       "step_definition": "one step = iterations_per_step pathtrace() iterations (1 in round 1, 16 since round 2): compare ms_per_iteration across rounds, not ms_per_step"},
             "device_ms_per_step": round(dev_ms / a.steps, 4), "ms_per_iteration": round(1e3 * elapsed / (a.steps * IPS), 4),
             "overlap_note": (f"{a.in_flight} iterations in flight on {a.in_flight} streams: ms_per_step is smaller than the sum of the "
                              "per-kernel times of one iteration (roofline.note) because iterations overlap") if a.in_flight > 1 else None,
@@ -444,14 +496,17 @@ def main():
             rec = pmc_record(a.scene) if (scene.width, scene.height) == (800, 800) and res is None and a.depth < 0 else None
             if rec:
                 per_iter = 0.0
-                for k, e in rec.items():
-                    c = e.get("counters") if isinstance(e, dict) else None
-                    if c and "SQ_ACTIVE_INST_VALU" in c and k != "counters":
-                        per_iter += c["SQ_ACTIVE_INST_VALU"] * (1 if k == "k_generate" else scene.trace_depth)
+                per_launch = ({"k_shade_trace": scene.trace_depth, "k_shade_trace_gen": 1} if a.pipeline in (0, 10) else
+                              {"k_intersect": scene.trace_depth, "k_shade_binned": scene.trace_depth, "k_generate": 1})
+                for k, mult in per_launch.items():
+                    c = (rec.get(k) or {}).get("counters") if isinstance(rec.get(k), dict) else None
+                    if c and "SQ_ACTIVE_INST_VALU" in c:
+                        per_iter += c["SQ_ACTIVE_INST_VALU"] * mult
                 cyc = 4.0 * per_iter / 1024.0
                 out["valu_busy_estimate"] = {"frac": round(cyc / (1e-3 * out["ms_per_iteration"] * 2.39e9), 3), "valu_active_cycles_per_simd_per_iteration": round(cyc),
                                              "clock_GHz_assumed": 2.39, "source": PMC_FILE,
-                                             "note": "the timed configuration is bound by vector-ALU issue, not by HBM: see roofline.counters and DESIGN.md section 5"}
+                                             "note": "VALU-active quad-cycles of the timed pipeline's kernels (single-stream PMC pass) over the wall time of one iteration; the "
+                                                     "counter charges every instruction one quad-cycle (packed and transcendental instructions issue longer: tools/diag/issue_cost.hip)"}
         out.update(extra)
         print(json.dumps(out))
     if N > 1:

@@ -167,7 +167,7 @@ struct TraceLds {
     int* cnt;                    // [NT / 64]
 };
 // RAYS_IN_LDS: L.ray already holds the rays (written by other threads of the block, a barrier since); else every thread stores its own
-template <int NT, bool RAYS_IN_LDS>
+template <int NT, bool RAYS_IN_LDS, int LP = 16>       // LP: primitives per pass of the pair list (list = NT * LP entries)
 __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, bool active, f3 ro, f3 rd, Analytic& a) {
     constexpr int NW = NT / 64;
     constexpr int RB = NT == 512 ? 9 : 8;                 // bits of the ray index inside a list entry
@@ -181,9 +181,9 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
     for (int base = 0; base < S.n_geoms; base += 32) {
         const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
         const Cand call = analytic_candidates(S, base, n, ro, rd);
-        for (int half = 0; half * 16 < n; ++half) {       // the pair list holds 16 primitives x NT rays
+        for (int half = 0; half * LP < n; ++half) {       // the pair list holds LP primitives x NT rays
             Cand c = call;
-            const unsigned hm = 0xffffu << (16 * half);
+            const unsigned hm = ((1u << LP) - 1u) << (LP * half);
             c.cube &= hm; c.sphere &= hm;
             if (!active) { c.cube = 0u; c.sphere = 0u; }
             // block-wide exclusive prefix of (cube count | sphere count << 16); a wave total is at most 64 * 16 per half
@@ -732,9 +732,9 @@ __device__ __forceinline__ int fetch_material_type(const SceneView& S, const Mat
     if (id < mt.n_lds) return mt.lds[id].type;
     return S.mats[id].type;
 }
-template <int NT>
+template <int NT, int MAXM = PTK_LDS_MATS>
 __device__ __forceinline__ MatTable stage_materials(const SceneView& S, DevMaterial* lds) {      // all threads of the block; ends with a barrier
-    const int n = S.n_mats < PTK_LDS_MATS ? S.n_mats : PTK_LDS_MATS;
+    const int n = S.n_mats < MAXM ? S.n_mats : MAXM;
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(S.mats);
     for (int j = threadIdx.x; j < n * (int)(sizeof(DevMaterial) / 4); j += NT) dst[j] = src[j];
@@ -1172,12 +1172,20 @@ __device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, con
 }
 
 template <int MODE, bool GEN, bool SPLIT>
-__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : 6)) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+#ifndef PTK_FUSED_WAVES_BSDF
+#define PTK_FUSED_WAVES_BSDF 7
+#endif
+__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE == PTK_MODE_DIRECTLI ? 6 : PTK_FUSED_WAVES_BSDF))) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
                                                              const int* __restrict__ d_n, TraceIO io, float* __restrict__ img_base, unsigned plane_stride,
                                                              int spp, int slot_bias, SegTail2 tail) {
     constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6;
-    // 8 KB shared by the two phases: shading = materials (5120 B) + permutation / slot / source tables (3 x 1 KB); tracing = pair list
-    __shared__ __attribute__((aligned(16))) unsigned char s_over[8192];
+    // Occupancy: 22.1 KB of LDS and <= 72 VGPRs = seven blocks per CU (with the 16-primitive pair list and 64 staged materials of the
+    // staged kernels: 25.9 KB = six; measured +x %).  MATS materials are staged (the rest, if any, come from global memory); the pair
+    // list takes LP primitives per pass.
+    constexpr int MATS = 16, LP = 8;
+    constexpr int OVER = (MATS * (int)sizeof(DevMaterial) + 3 * NT * (int)sizeof(int)) > NT * LP * 2 ? (MATS * (int)sizeof(DevMaterial) + 3 * NT * (int)sizeof(int)) : NT * LP * 2;
+    // shared by the two phases: shading = materials + permutation / slot / source tables (3 x 1 KB); tracing = pair list
+    __shared__ __attribute__((aligned(16))) unsigned char s_over[OVER];
     __shared__ float4 s_ray[2 * NT];
     __shared__ float2 s_res[3 * NT];
     __shared__ unsigned long long s_best[NT];
@@ -1185,10 +1193,9 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : 6)) k_s
     __shared__ int s_red[NW];
     __shared__ int s_tcnt[NW];
     DevMaterial* s_mats = reinterpret_cast<DevMaterial*>(s_over);
-    int* s_perm = reinterpret_cast<int*>(s_over + PTK_LDS_MATS * sizeof(DevMaterial));
+    int* s_perm = reinterpret_cast<int*>(s_over + MATS * sizeof(DevMaterial));
     int* s_slot = s_perm + NT;
     int* s_src = s_slot + NT;
-    static_assert(PTK_LDS_MATS * sizeof(DevMaterial) + 3 * NT * sizeof(int) <= 8192 && NT * 16 * sizeof(unsigned short) <= 8192, "phase overlay");
     const TraceLds L = {s_ray, s_res, s_best, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
 
     const int step = iter_ptr ? *iter_ptr : iter_arg;
@@ -1232,7 +1239,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : 6)) k_s
     } else {
         // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
         const int iter = (step - 1) * spp + 1;
-        const MatTable mt = stage_materials<NT>(S, s_mats);
+        const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
         int hit_base = 0;
         const int src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, hit_base);      // 0 for i >= n
         const int hr = (i < n) ? io.hr_cur[src_mine] : -1;
@@ -1309,7 +1316,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : 6)) k_s
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
         if (active) { const float4 o4 = s_ray[2 * tid], d4 = s_ray[2 * tid + 1]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z); }
         Analytic a;
-        if (gs.on) analytic_closest_lds<NT, true>(S, gs, L, active, ro, rd, a);
+        if (gs.on) analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
         else { a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0); if (active) analytic_closest(S, gs, ro, rd, a); }
         int flag = 0;
         bool heavy = false;

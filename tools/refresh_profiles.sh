@@ -1,30 +1,43 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'): refreshes every measurement the docs cite into
-# gpurun_out/final_r2/ (copy the summaries into profiles/ afterwards: tools/collect_profiles.py).
-#   kernel stats : rocprofv3 --kernel-trace --stats of `python3 bench.py` (cornell = the default line, then the BVH scene)
+# gpurun_out/final_r3/ (copy the summaries into profiles/ afterwards: python3 tools/collect_profiles.py).
+#   kernel stats : rocprofv3 --kernel-trace --stats of `python3 bench.py` (cornell = the default line, then the BVH scene), in the timed
+#                  configuration (3 iterations in flight, graph replay) and single-stream for both pipelines (0 = fused default, 8 = staged)
 #   PMC          : rocprofv3 --pmc, separate passes with --kernel-trace only (never with a sys/hip/hsa trace), single stream, eager launches:
-#                  FETCH_SIZE, WRITE_SIZE (one counter per pass) and two SQ passes (VALU / wave occupancy / LDS)
-#   bench        : the plain default `python3 bench.py` line
+#                  FETCH_SIZE, WRITE_SIZE (one counter per pass) and two SQ passes (VALU / wave occupancy / LDS), per pipeline;
+#                  one SQ pass of the contracted flavour (libptk_fma.so)
+#   bench        : the plain default `python3 bench.py` line, and the driver-style `--steps 20 --warmup 5`
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/final_r2
+out=$R/gpurun_out/final_r3
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $R
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
 SQ2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+LEAN="--bvh-scene \"\" --cpu-seconds 0 --lean 1 --profile-steps 1"
 for sc in cornell.txt bunny_cornell.txt; do
   tag=${sc%%.txt}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$tag -o trace -- python3 bench.py --scene $sc --bvh-scene "" --cpu-seconds 1 > $out/bench_under_rocprof_$tag.json 2> $out/stats_$tag.err || exit 1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1_$tag -o trace -- python3 bench.py --scene $sc --bvh-scene "" --cpu-seconds 0.1 --in-flight 1 --graph 0 > $out/bench_under_rocprof_inflight1_$tag.json 2> $out/stats1_$tag.err || exit 1
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${ctr}_$tag -o pmc -- python3 bench.py --scene $sc --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0.1 --profile-steps 1 --in-flight 1 --graph 0 > /dev/null 2> $out/pmc_${ctr}_$tag.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$tag -o trace -- python3 bench.py --scene $sc --bvh-scene "" --cpu-seconds 0 --lean 1 > $out/bench_under_rocprof_$tag.json 2> $out/stats_$tag.err || exit 1
+  for p in 0 8; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1_${tag}_p$p -o trace -- python3 bench.py --scene $sc --bvh-scene "" --cpu-seconds 0 --lean 1 --in-flight 1 --graph 0 --pipeline $p > $out/bench_under_rocprof_inflight1_${tag}_p$p.json 2> $out/stats1_${tag}_p$p.err || exit 1
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${ctr}_${tag}_p$p -o pmc -- python3 bench.py --scene $sc --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0 --lean 1 --profile-steps 1 --in-flight 1 --graph 0 --pipeline $p > /dev/null 2> $out/pmc_${ctr}_${tag}_p$p.err || exit 1
+    done
+    rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $out/pmc_SQ1_${tag}_p$p -o pmc -- python3 bench.py --scene $sc --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0 --lean 1 --profile-steps 1 --in-flight 1 --graph 0 --pipeline $p > /dev/null 2> $out/pmc_SQ1_${tag}_p$p.err || exit 1
+    rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $out/pmc_SQ2_${tag}_p$p -o pmc -- python3 bench.py --scene $sc --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0 --lean 1 --profile-steps 1 --in-flight 1 --graph 0 --pipeline $p > /dev/null 2> $out/pmc_SQ2_${tag}_p$p.err || exit 1
   done
-  rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $out/pmc_SQ1_$tag -o pmc -- python3 bench.py --scene $sc --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0.1 --profile-steps 1 --in-flight 1 --graph 0 > /dev/null 2> $out/pmc_SQ1_$tag.err || exit 1
-  rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $out/pmc_SQ2_$tag -o pmc -- python3 bench.py --scene $sc --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0.1 --profile-steps 1 --in-flight 1 --graph 0 > /dev/null 2> $out/pmc_SQ2_$tag.err || exit 1
   echo "done $sc"
 done
+# the contracted flavour: how many VALU instructions -ffp-contract=fast removes
+for p in 0 8; do
+  PTK_FLAVOUR=fma rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $out/pmc_SQ1_cornell_fma_p$p -o pmc -- python3 bench.py --bvh-scene "" --steps 4 --warmup 1 --cpu-seconds 0 --lean 1 --profile-steps 1 --in-flight 1 --graph 0 --pipeline $p > /dev/null 2> $out/pmc_SQ1_cornell_fma_p$p.err || exit 1
+done
+python3 tools/pmc_traffic.py $out > $out/r3_pmc.json || exit 1
+cp $out/r3_pmc.json profiles/r3_pmc.json          # bench.py reads the committed summary: use the fresh one for the two lines below
+python3 tools/collect_profiles.py > /dev/null
 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
-python3 tools/pmc_traffic.py $out > $out/r2_pmc.json || exit 1
+python3 bench.py --steps 20 --warmup 5 > $out/bench_driver_style.json 2> $out/bench_driver_style.err || exit 1
+./tools/diag/issue_cost.bin > $out/issue_cost.txt 2>&1 || true
 find $out -name "*.csv" -size +2M -delete
 tail -c 600 $out/bench.json
