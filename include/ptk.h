@@ -179,8 +179,6 @@ int ptk_set_shade_binning(int block);
  * area -> solid-angle pdf of a triangle light, and lightPDF returns the same for a BSDF-sampled hit; MIS and BSDF renders
  * then converge to the same image.  Default 0 = reference behaviour.  Applies to the kernels launched afterwards. */
 int ptk_set_light_fix(int on);
-/* Threads per block of the fused bounce kernel (pipeline 3): 256 (default) or 512.  Identical results. */
-int ptk_set_fused_block(int threads);
 /* 1: replay every iteration from a hipGraph captured once per lane (the kernels then read the iteration number from device
  * memory); 0 (default): launch the kernels one by one.  Identical results; cuts the host cost per iteration. */
 int ptk_set_graph_replay(int on);
@@ -232,9 +230,8 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *   1 = like 7, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
  *   2 = like 1, and analytic primitives are tested with wave-uniform loops over every primitive instead of the LDS-staged
  *       candidate pair lists;
- *   3 = ticketed fusion: one kernel per bounce (closest hit, shading and both stable compactions through two chained scans with
- *       ticketed block ids; the hit record never leaves registers).  Least memory traffic, but the ticket counter
- *       serialises block starts (~11 ns each): slower than 0 on MI355X at the BASELINE sizes;
+ *   3 = (removed in round 3; PTK_E_BADARG) the ticketed one-kernel-per-bounce fusion of rounds 1-2, whose ticket counter serialised
+ *       block starts; k_shade_trace fuses without any inter-block communication;
  *   4 = like 7 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables;
  *   5 = like 7/8, the work-list rays walk the reference's threaded 6-direction BVH, one ray per lane (the others walk the 8-wide
  *       collapsed form of the same tree, several lanes per ray, csrc/wide_bvh.h); 6 = the wide walk with the staged kernels;
@@ -244,7 +241,7 @@ int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 
 /* Per-kernel device time, measured with HIP events ON THE RENDER STREAM around every launch of the ptk_pathtrace calls
- * issued between begin and end.  ms4/launches4: [0] generate, [1] intersect (pipeline 3: the fused kernel), [2] shade, [3] compact (k_segments / k_scatter).  Diagnostic only
+ * issued between begin and end.  ms4/launches4: [0] generate, [1] intersect (pipeline 0: the work-list BVH stage and k_tail), [2] shade (pipeline 0: k_shade_trace; its first launch of an iteration counts as generate), [3] compact (k_segments / k_scatter).  Diagnostic only
  * (adds an event pair per launch): never used inside a timed region. */
 int ptk_profile_begin(void);
 int ptk_profile_end(float* ms4, int* launches4);

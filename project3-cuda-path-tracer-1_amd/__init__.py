@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
-    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_fused_block", "ptk_set_light_fix",
+    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_light_fix",
     "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_debug_slot_shift", "ptk_debug_clear_image", "ptk_debug_exact_math",
 ]
 
@@ -140,7 +140,6 @@ def _load() -> C.CDLL:
     lib.ptk_set_graph_replay.argtypes = [ci]
     lib.ptk_set_samples_per_launch.argtypes = [ci]
     lib.ptk_set_shade_binning.argtypes = [ci]
-    lib.ptk_set_fused_block.argtypes = [ci]
     lib.ptk_set_light_fix.argtypes = [ci]
     lib.ptk_set_iteration_sharding.argtypes = [ci, ci]
     lib.ptk_get_full_width_bounces.argtypes = [C.POINTER(ci)]

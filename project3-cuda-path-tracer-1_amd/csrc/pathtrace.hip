@@ -101,7 +101,6 @@ int context_free() {
         dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
-        dfree(l.ws.ticket); dfree(l.ws.epoch); dfree(l.ws.st_hit); dfree(l.ws.st_live);
         dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
         if (l.graph) (void)hipGraphDestroy(l.graph);
@@ -182,25 +181,12 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
     if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
     l.ws.seg_done = fold_segments(g.pipeline, g.n_lanes) ? l.seg_done_mem : nullptr;
-    if ((rc = dalloc(&l.ws.ticket, 1))) return rc;
-    if ((rc = dalloc(&l.ws.epoch, 1))) return rc;
-    if ((rc = dalloc(&l.ws.st_hit, blocks))) return rc;
-    if ((rc = dalloc(&l.ws.st_live, blocks))) return rc;
-    {
-        const unsigned one = 1u;                 // tag 0 never matches: the zeroed tables read as "not published"
-        if ((e = hipMemsetAsync(l.ws.ticket, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
-        if ((e = hipMemcpyAsync(l.ws.epoch, &one, sizeof(unsigned), hipMemcpyHostToDevice, l.stream)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(l.ws.st_hit, 0, sizeof(unsigned long long) * blocks, l.stream)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(l.ws.st_live, 0, sizeof(unsigned long long) * blocks, l.stream)) != hipSuccess) return (int)e;
-        if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) return (int)e;
-    }
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
-    l.ws.inline_bvh = (g.pipeline != 0 && g.pipeline < 4);
+    l.ws.inline_bvh = (g.pipeline == 1 || g.pipeline == 2);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4;          // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
-    l.ws.fused = (g.pipeline == 3);
     l.ws.segmented = (g.pipeline != 4);
     l.ws.capacity = g.capacity;
     l.last_iter = 0;
@@ -262,7 +248,7 @@ void prof_mark(int cls, bool begin) {
 }
 
 // k_tail finishes the iterations of the default (segmented) pipelines; pipeline 9 = every bounce at full width (A/B)
-bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 3 && g.pipeline != 4 && g.pipeline != 1 && g.pipeline != 2 && !g_prof.on &&
+bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 4 && g.pipeline != 1 && g.pipeline != 2 && !g_prof.on &&
                             !(g.lanes.size() && g.lanes[0].ws.stats); }
 // the fused shade + trace launches (default); the traversal counters are only kept by the staged kernels
 bool use_trace_pipeline() { return trace_pipeline(g.pipeline) && !(g.lanes.size() && g.lanes[0].ws.stats); }
@@ -301,11 +287,7 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     PtkPaths cur = L.bufA, nxt = L.bufB;
     for (int depth = 0; depth < full; ++depth) {
         const bool last = depth == g.traceDepth - 1;      // false for every full-width bounce when k_tail follows: it steps the iteration number
-        if (ws.fused) {
-            prof_mark(1, true);      // the fused kernel is reported in the intersect class
-            rc = launch_bounce_fused(S, mode, iter, depth, g.capacity, cur, nxt, L.plane, ws, L.stream, last);
-            prof_mark(1, false);
-        } else if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
+        if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
         else rc = launch_bounce_staged(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, last);
         if (rc) return rc;
         PtkPaths t = cur; cur = nxt; nxt = t;
@@ -483,7 +465,6 @@ static void invalidate_graphs() { for (Lane& l : g.lanes) l.graph_mode = -1; }  
 int ptk_set_shade_binning(int block) { if (block != 0 && block != 256) return PTK_E_BADARG; set_shade_bin(block); invalidate_graphs(); return 0; }
 /* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
 int ptk_set_light_fix(int on) { set_light_fix(on != 0); invalidate_graphs(); return 0; }
-int ptk_set_fused_block(int threads) { if (threads != 256 && threads != 512) return PTK_E_BADARG; set_fused_block(threads); invalidate_graphs(); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
 int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
 
@@ -585,9 +566,9 @@ int ptk_debug_clear_image(void) {
     return rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
 }
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 10) return PTK_E_BADARG;
+    if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which != 0 && which < 4); l.ws.fused = (which == 3); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which == 1 || which == 2); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     return 0;

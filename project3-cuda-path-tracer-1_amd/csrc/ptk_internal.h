@@ -57,10 +57,6 @@ struct Workspace {               // per-render-context scratch, device memory
     int spp = 1;                 // samples (iterations) per launch
     int slot_bias = 0;           // added to the compacted slot in the shading RNG key: part * W * H * spp under the tile partition, so
                                  // that two ranks never share a random stream (0 on one GPU = the reference's key)
-    // fused bounce kernel (pipeline 3): ticket counter, launch tag and the two scan status tables [blocks]
-    unsigned* ticket = nullptr; unsigned* epoch = nullptr;
-    unsigned long long* st_hit = nullptr; unsigned long long* st_live = nullptr;
-    bool fused = false;          // pipeline 3
     // segmented path streams (default): physical slot of every dense path, window prefix and first-window tables
     int* srcidx = nullptr; int* seg_pref = nullptr; int* seg_first = nullptr;
     int* seg_done = nullptr;     // blocks of the running shading kernel that have published their survivor count (segments_tail); null:
@@ -80,8 +76,6 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
                          PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce);
 int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt,
                                   PtkHits hits, float* img, const Workspace& ws, hipStream_t st, void (*mark)(int, bool), bool last_bounce);
-int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img,
-                        const Workspace& ws, hipStream_t st, bool last_bounce);
 int launch_tail(const SceneView& S, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
                 const Workspace& ws, hipStream_t st, const PtkHits* hits0 = nullptr, const int* hr0 = nullptr);
 // fused pipeline (k_shade_trace): shade bounce dt - 1 of `cur` (gen: generate the camera rays instead) and trace bounce dt into `nxt`
@@ -89,7 +83,6 @@ struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; };
 int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool));
-void set_fused_block(int nt);
 void set_shade_bin(int nt);
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);

@@ -9,7 +9,7 @@
 //                                                            of the survivors + segments_tail / k_segments (window tables); k_count + k_scatter
 //                                                            remain as the stand-alone stable compaction (ptk_compact, pipeline 4)
 //   sendImageToPBO (32-65)                                -> k_tonemap
-//   (whole bounce in one launch, A/B only)                -> k_bounce (pipeline 3)
+//   (shade bounce d-1 + trace bounce d in one launch)     -> k_shade_trace (default render kernel)
 //   (the sparse end of an iteration in one launch)        -> k_tail
 // What is specific to MI355X:
 //   * 256-thread blocks = 4 wave64; all state streams are float4 SoA (16 B/lane, 1 KiB per wave access);
@@ -1399,76 +1399,6 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_scatter(int n_arg, const int* __r
     if (count_out && threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *count_out = prior + total;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Fused bounce (pipeline 3): computeIntersections + compact + shade + compact of pathtrace.cu:700-790 in ONE launch.
-//
-// Each path stays in registers from its ray to its scattered successor: the hit record is never written, and the two
-// order-preserving compactions of the reference become two single-pass chained scans ("decoupled look-back") over the
-// blocks of the launch:
-//   scan 1 (hits)      gives every hit path its compacted slot == the reference's RNG key for the shading kernels;
-//   scan 2 (survivors) gives every surviving path its position in the next bounce's stream (stable, like thrust).
-// HBM traffic per path-bounce: 48 B in + 48 B out for survivors (+ the radiance read-modify-write), instead of the staged
-// layout's 76 + 152 + ~100 B, and one launch per bounce instead of three.
-//
-// Scan protocol (inter-workgroup, MI355X_MICROARCH "inter-workgroup visibility"): one 8-byte granule per block and scan,
-// {tag:32 | kind:2 | value:30}, written by ONE agent-scope relaxed store (sc1) and polled with agent-scope relaxed loads by
-// wave 0 of the waiting block; the payload is inside the granule, so no fence is needed.  kind 1 = this block's aggregate,
-// kind 2 = inclusive prefix.  `tag` is a per-launch number from a device counter, so the tables never need clearing.
-// Logical block ids come from a ticket counter (not blockIdx), so a block can only ever wait for blocks that are already
-// running — progress does not depend on dispatch order or on what other streams' kernels occupy the CUs.  Blocks beyond
-// the live count exit before drawing a ticket.  The block that draws the last ticket resets the ticket, steps the tag
-// and (last bounce) the device-resident iteration number: every participating block has read those words by then,
-// because thread 0 reads them BEFORE drawing its ticket and hands them to the block through LDS.
-// ------------------------------------------------------------------------------------------------------------------
-#define PTK_SCAN_AGG 1u
-#define PTK_SCAN_PREFIX 2u
-__device__ __forceinline__ unsigned long long scan_pack(unsigned tag, unsigned kind, int value) {
-    return ((unsigned long long)tag << 32) | ((unsigned long long)kind << 30) | (unsigned)value;
-}
-
-// exclusive prefix over the logical blocks before `b` of the per-block totals; publishes this block's own status.
-// Called by every thread of the block (contains barriers).  Values are < 2^30.
-template <int NT>
-__device__ __forceinline__ int lookback_exclusive(unsigned long long* __restrict__ st, unsigned tag, int b, int total) {
-    __shared__ int s_excl;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_store(&st[b], scan_pack(tag, b == 0 ? PTK_SCAN_PREFIX : PTK_SCAN_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int excl = 0;
-        if (b > 0) {
-            int pos = b - 1;                                   // lane 0 examines the nearest predecessor
-            for (;;) {
-                const int idx = pos - lane;
-                unsigned long long w = scan_pack(tag, PTK_SCAN_PREFIX, 0);      // "before block 0": prefix 0
-                bool ready = idx < 0;
-                for (;;) {
-                    if (!ready) {
-                        w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ready = (unsigned)(w >> 32) == tag;
-                    }
-                    if (__ballot(!ready) == 0ull) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                const unsigned kind = (unsigned)(w >> 30) & 3u;
-                const unsigned long long pm = __ballot(kind == PTK_SCAN_PREFIX);
-                const int first = pm ? (int)__builtin_ctzll(pm) : 63;          // nearest predecessor holding an inclusive prefix
-                int v = (lane <= first) ? (int)((unsigned)w & 0x3FFFFFFFu) : 0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                excl += v;
-                if (pm) break;
-                pos -= 64;
-            }
-            if (lane == 0) __hip_atomic_store(&st[b], scan_pack(tag, PTK_SCAN_PREFIX, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) s_excl = excl;
-    }
-    __syncthreads();
-    const int r = s_excl;
-    __syncthreads();
-    return r;
-}
-
 template <int NT>
 __device__ __forceinline__ int block_excl_prefix_n(int flag, int& total) {
     constexpr int NW = NT / 64;
@@ -1484,106 +1414,6 @@ __device__ __forceinline__ int block_excl_prefix_n(int flag, int& total) {
     __syncthreads();
     total = tot;
     return off + within;
-}
-
-// Logical block id of a chained-scan kernel (see k_bounce).  Thread 0 reads the live count, the iteration number and the
-// launch tag, THEN draws the ticket, and hands all four to the block through LDS.  Blocks beyond the live count get b = -1.
-// The block that draws the last ticket resets the ticket, steps the tag and performs the once-per-launch updates.
-template <int NT>
-__device__ __forceinline__ void draw_ticket(const int* d_n, int n_arg, const int* iter_ptr, int iter_arg, unsigned* ticket_ctr, unsigned* epoch,
-                                            int* iter_advance, int iter_stride, unsigned long long* ray_total, int* count_out,
-                                            int& b, unsigned& tag, int& n, int& step) {
-    __shared__ int s_hdr[4];                 // ticket, tag, n, step
-    if (threadIdx.x == 0) {
-        const int n0 = d_n ? *d_n : n_arg;
-        const int step0 = iter_ptr ? *iter_ptr : iter_arg;
-        const unsigned tag0 = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ticket = -1;
-        const int nb = n0 > 0 ? (n0 + NT - 1) / NT : 0;
-        if ((int)blockIdx.x < nb || (nb == 0 && blockIdx.x == 0)) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // n, step, tag are in registers before the ticket is drawn
-            if (nb > 0) ticket = (int)atomicAdd(ticket_ctr, 1u);
-            if (nb == 0 || ticket == nb - 1) {                               // every participating block holds its ticket and has read the words above
-                __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(epoch, tag0 + 1u == 0u ? 1u : tag0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (iter_advance) *iter_advance += iter_stride;
-                if (ray_total && n0 > 0) atomicAdd(ray_total, (unsigned long long)n0);
-                if (nb == 0 && count_out) *count_out = 0;
-            }
-        }
-        s_hdr[0] = ticket; s_hdr[1] = (int)tag0; s_hdr[2] = n0; s_hdr[3] = step0;
-    }
-    __syncthreads();
-    b = s_hdr[0]; tag = (unsigned)s_hdr[1]; n = s_hdr[2]; step = s_hdr[3];
-}
-
-struct FusedArgs {
-    int iter_arg; const int* iter_ptr; int depth;
-    int n_arg; const int* d_n;
-    PtkPaths cur, nxt;
-    float* img; unsigned plane_stride; int spp; int slot_bias;
-    int* count_out;                          // live paths entering the next bounce
-    unsigned long long* ray_total;
-    unsigned long long* stats;
-    unsigned* ticket; unsigned* epoch;       // LookBack state of this lane (ptk_internal.h)
-    unsigned long long* st_hit; unsigned long long* st_live;
-    int* iter_advance; int iter_stride;      // last bounce of an iteration: step the device-resident iteration number
-};
-
-template <int MODE, bool STATS, int NT>
-__global__ void __launch_bounds__(NT) k_bounce(SceneView S, FusedArgs A) {
-    int b, n, step;
-    unsigned tag;
-    draw_ticket<NT>(A.d_n, A.n_arg, A.iter_ptr, A.iter_arg, A.ticket, A.epoch, A.iter_advance, A.iter_stride, A.ray_total, A.count_out, b, tag, n, step);
-    const int iter = (step - 1) * A.spp + 1;
-    if (b < 0) return;
-    const GeomStage gs = stage_geoms(S);
-    const Film img = {A.img, A.plane_stride};
-    const int i = b * NT + threadIdx.x;
-    // ---- phase A: closest hit (computeIntersections) -------------------------------------------------------------
-    int flag = 0;
-    unsigned nv = 0, nt = 0;
-    Hit h;
-    PathRegs p;
-    h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
-    p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
-    if (i < n) {
-        const float4 o4 = ld4(A.cur.o_pix, i), d4 = ld4(A.cur.d_bnc, i);
-        p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
-        p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
-        flag = closest_hit<STATS>(S, gs, p.o, p.d, h, nv, nt);
-        if (!flag && S.env_tex >= 0) {                                  // environment map on a miss (pathtrace.cu:303-311)
-            const float4 c4 = ld4(A.cur.col_pdf, i);
-            add_radiance(img, p.pix, nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, p.d)));
-        }
-    }
-    int total;
-    const int local = block_excl_prefix_n<NT>(flag, total);
-    const int prior = lookback_exclusive<NT>(A.st_hit, tag, b, total);
-    // ---- phase B: shade the hits, keyed by their compacted slot ----------------------------------------------------
-    int alive = 0;
-    if (flag) {
-        const float4 c4 = ld4(A.cur.col_pdf, i);
-        p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-        const MatTable mt = {nullptr, 0};
-        alive = shade_path<MODE>(S, gs, mt, iter, prior + local + A.slot_bias, A.depth, h, p, img);
-    }
-    int total2;
-    const int local2 = block_excl_prefix_n<NT>(alive, total2);
-    const int prior2 = lookback_exclusive<NT>(A.st_live, tag, b, total2);
-    if (alive) {
-        const int s = prior2 + local2;
-        st4(A.nxt.o_pix, s, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
-        st4(A.nxt.d_bnc, s, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
-        st4(A.nxt.col_pdf, s, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
-    }
-    if (A.count_out && threadIdx.x == 0 && b == (n - 1) / NT) *A.count_out = prior2 + total2;
-    if (STATS && A.stats) {
-        unsigned long long a = nv, c = nt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&A.stats[0], a); atomicAdd(&A.stats[1], c); }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1852,22 +1682,6 @@ int* g_abi_list = nullptr;
 int g_abi_list_cap = 0;
 int* g_abi_hflag = nullptr;             // work-list flags / per-block counts of the same entry point (same layout as the render loop)
 int* g_abi_hagg = nullptr;
-int g_fused_block = 256;               // threads per block of k_bounce (256 or 512)
-
-template <int MODE, int NT>
-int launch_fused_nt(const SceneView& S, const FusedArgs& A, int capacity, bool stats, hipStream_t st) {
-    const int g = (capacity + NT - 1) / NT;
-    if (g == 0) return 0;
-    if (stats) k_bounce<MODE, true, NT><<<g, NT, stage_bytes(S), st>>>(S, A);
-    else k_bounce<MODE, false, NT><<<g, NT, stage_bytes(S), st>>>(S, A);
-    return launch_rc();
-}
-template <int MODE>
-int launch_fused_mode(const SceneView& S, const FusedArgs& A, int capacity, bool stats, hipStream_t st) {
-    if (g_fused_block == 512) return launch_fused_nt<MODE, 512>(S, A, capacity, stats, st);
-    return launch_fused_nt<MODE, 256>(S, A, capacity, stats, st);
-}
-
 bool g_uniform_analytic = false;       // A/B switch: wave-uniform loops over every analytic primitive (no LDS staging, no candidate test)
 
 // scratch for the stand-alone ptk_compact entry point (per-block aggregates), grown on demand
@@ -1984,26 +1798,6 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
                          PtkHits hits, float* img, const Workspace& ws, hipStream_t st, bool last_bounce) {
     return launch_bounce_staged_profiled(S, mode, iter, depth, capacity, cur, nxt, hits, img, ws, st, no_mark, last_bounce);
 }
-// one bounce of the fused pipeline (k_bounce): a single launch
-int launch_bounce_fused(const SceneView& S, int mode, int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img,
-                        const Workspace& ws, hipStream_t st, bool last_bounce) {
-    if (!ws.ticket || !ws.epoch || !ws.st_hit || !ws.st_live) return PTK_E_BADARG;
-    FusedArgs A;
-    A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth = depth;
-    A.n_arg = capacity; A.d_n = ws.counts + depth;
-    A.cur = cur; A.nxt = nxt;
-    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
-    A.count_out = ws.counts + depth + 1;
-    A.ray_total = ws.ray_total; A.stats = ws.stats;
-    A.ticket = ws.ticket; A.epoch = ws.epoch; A.st_hit = ws.st_hit; A.st_live = ws.st_live;
-    A.iter_advance = last_bounce ? ws.iter_dev : nullptr; A.iter_stride = ws.iter_stride;
-    switch (mode) {
-    case PTK_MODE_BSDF: return launch_fused_mode<PTK_MODE_BSDF>(S, A, capacity, ws.stats != nullptr, st);
-    case PTK_MODE_DIRECTLI: return launch_fused_mode<PTK_MODE_DIRECTLI>(S, A, capacity, ws.stats != nullptr, st);
-    case PTK_MODE_MIS: return launch_fused_mode<PTK_MODE_MIS>(S, A, capacity, ws.stats != nullptr, st);
-    default: return PTK_E_BADARG;
-    }
-}
 // fused pipeline: one launch shades bounce dt - 1 (paths / hits / ranks of `cur`) — or, gen, generates the camera rays — and traces
 // bounce dt into `nxt`.  Scenes with triangles continue with the work-list BVH stage on the survivors' physical slots.
 template <int MODE, bool GEN>
@@ -2102,7 +1896,6 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     }
     return launch_rc();
 }
-void set_fused_block(int nt) { g_fused_block = (nt == 512) ? 512 : 256; }
 bool g_light_fix = false;
 void set_light_fix(bool on) { g_light_fix = on; }
 bool light_fix_enabled() { return g_light_fix; }

@@ -183,10 +183,10 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("pipeline", [1, 2, 4, 5, 6, 7, 8, 9, 10])
 def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
     """ptk_set_pipeline variants (1 = staged kernels with the BVH walked inside the intersect kernel, 2 = the same with wave-uniform
-    loops over every analytic primitive instead of the staged candidate loops, 3 = the fused bounce kernel with chained scans,
+    loops over every analytic primitive instead of the staged candidate loops,
     4 = staged intersect + shading that compacts its survivors through one chained scan, 5 = default pipeline with the work-list
     rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree with four lanes per ray, 7 / 8 = default pipeline with the
     window bookkeeping in a separate k_segments launch / in the shading kernel's last block, 9 = every bounce at full width (no k_tail),
@@ -779,7 +779,7 @@ def test_degenerate_scenes(ptk, orc, torch_cuda, tmp_path):
             o = orc.Scene(str(f))
             ref = np.zeros((o.P, 3), np.float32)
             lives = [o.pathtrace(mode, it, ref)[1] for it in (1, 2)]
-            for pipeline in (0, 3, 4):
+            for pipeline in (0, 8, 4):
                 s = ptk.Scene(str(f))
                 r = ptk.Renderer(s, mode, pipeline=pipeline)
                 for k, it in enumerate((1, 2)):

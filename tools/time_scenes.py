@@ -18,10 +18,7 @@ def run(scn, mode=0, lanes=1, pipeline=0, steps=32, res=None, depth=-1, graph=Tr
 
 if __name__ == "__main__":
     pipes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
-    fb = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256]
     for scn, mode in (("cornell.txt", 0), ("cornell.txt", 2), ("mis_test.txt", 2), ("bunny_cornell.txt", 0), ("metallic_analytic.txt", 0)):
         for pipe in pipes:
-            for nt in (fb if pipe == 3 else [256]):
-                ptk.lib.ptk_set_fused_block(nt)
-                for lanes in (1, 2, 3, 4):
-                    print(scn, "mode", mode, "pipe", pipe, "fb", nt, "L", lanes, run(scn, mode, lanes, pipeline=pipe), flush=True)
+            for lanes in (1, 2, 3, 4):
+                print(scn, "mode", mode, "pipe", pipe, "L", lanes, run(scn, mode, lanes, pipeline=pipe), flush=True)
