@@ -142,7 +142,7 @@ def test_two_rank_iteration_sharding_is_the_single_process_render(tmp_path, orc,
 
 def test_bench_self_launch_starts_ranks_without_gpu(tmp_path):
     """`python bench.py --gpus 2` from a plain shell starts the ranks itself (no WORLD_SIZE needed).  Without a GPU every rank stops
-    at 'needs a GPU' — the point here is that the launcher ran both ranks and handed their exit code on (the rc-0 run with its JSON
+    at 'needs a GPU' — the point here is that the launcher started the ranks and handed their exit code on (the rc-0 run with its JSON
     line is the -m gpu test tests/test_gpu_multirank.py::test_bench_self_launches_two_ranks)."""
     import subprocess
     if torch.cuda.is_available():
@@ -151,5 +151,6 @@ def test_bench_self_launch_starts_ranks_without_gpu(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    # (torchrun stops the other rank as soon as one has failed: at least one of them got as far as the GPU check)
+    assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]
     assert "launch with: python -m torch.distributed.run" not in r.stderr
