@@ -146,7 +146,7 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * ((size_t)g.traceDepth + 2), hipHostMallocDefault)) != hipSuccess) return (int)e;
     l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
-    l.ws.plane_stride = 3u * (unsigned)g.P;
+    l.ws.plane_stride = g.spp > 1 ? 3u * (unsigned)g.P : 0u;      // 0: no sample-plane bits in pixelIndex (pixel_ptr, ptk_kernels.hip)
     l.ws.spp = g.spp;
     // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
     l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;          // fits an int: checked in context_init
@@ -206,7 +206,8 @@ int context_init(Scene* scene) {
     if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
     g.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
     g.capacity = g.n_pix * g.spp;
-    if (g.P >= (1 << 24)) return PTK_E_BADARG;            // pixelIndex carries the sample plane in bits 24..30
+    if (g.spp > 1 && g.P >= (1 << 24)) return PTK_E_BADARG;      // samples per launch: pixelIndex carries the sample plane in bits 24..30
+    if (g.P > (1 << 29)) return PTK_E_BADARG;                    // 32-bit float offsets into a plane
     // the rank-unique RNG key is slot + part * P * spp as a 32-bit int; refuse partitions whose largest key would wrap
     if (g.n_parts > 1 && (long long)g.part * g.P * g.spp + (long long)g.capacity > 2147483647LL) return PTK_E_BADARG;
     int rc;

@@ -115,6 +115,13 @@ __device__ __forceinline__ int prefix_block(int nw, const int* __restrict__ agg,
     return total;
 }
 
+// pixelIndex -> its three floats in the radiance planes.  With samples per launch (spp > 1) bits 24..30 of pixelIndex carry the sample's
+// plane; a launch with spp == 1 passes plane_stride = 0 and all 31 bits are the pixel (frames of 2^24 pixels and more).  Wave-uniform selects.
+__device__ __forceinline__ float* pixel_ptr(float* img, unsigned plane_stride, int pix) {
+    const unsigned mask = plane_stride ? 0xFFFFFFu : 0x7FFFFFFFu;
+    const unsigned plane = plane_stride ? ((unsigned)pix >> 24) : 0u;
+    return img + (size_t)plane * plane_stride + 3 * (size_t)((unsigned)pix & mask);
+}
 __device__ __forceinline__ float4 ld4(const float* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
 __device__ __forceinline__ void st4(float* p, int i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
 
@@ -688,7 +695,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg,
     const float4 d4 = ld4(paths.d_bnc, g), c4 = ld4(paths.col_pdf, g);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)g + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
-    float* p = img + (size_t)(pix >> 24) * plane_stride + 3 * (size_t)(pix & 0xFFFFFF);
+    float* p = pixel_ptr(img, plane_stride, pix);
     p[0] += c.x; p[1] += c.y; p[2] += c.z;
 }
 
@@ -703,7 +710,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, 
     const float4 d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)i + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
-    float* p = img + (size_t)(pix >> 24) * plane_stride + 3 * (size_t)(pix & 0xFFFFFF);
+    float* p = pixel_ptr(img, plane_stride, pix);
     p[0] += c.x; p[1] += c.y; p[2] += c.z;
 }
 
@@ -716,7 +723,7 @@ struct PathRegs { f3 o, d, col; int pix, bounces; float prevPdf; };
 struct Film { float* img; unsigned plane_stride; };       // radiance planes: float[plane][3*P]
 __device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
     // one live path per (sample plane, pixel): plain read-modify-write, no atomics.  plane = pix >> 24 (0 unless spp > 1)
-    float* p = film.img + (size_t)(pix >> 24) * film.plane_stride + 3 * (size_t)(pix & 0xFFFFFF);
+    float* p = pixel_ptr(film.img, film.plane_stride, pix);
     p[0] += c.x; p[1] += c.y; p[2] += c.z;
 }
 

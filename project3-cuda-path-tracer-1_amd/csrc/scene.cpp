@@ -534,8 +534,9 @@ int Scene::loadCamera(std::istream& in) {                             // scene.c
         readLine(in, line);
     }
     if (cam.resolution.x <= 0 || cam.resolution.y <= 0) { error = "CAMERA block without a valid RES line"; return -2; }
-    // pixelIndex shares its word with the sample plane (bits 24..30) and the image is 12 B per pixel on host and device
-    if ((long long)cam.resolution.x * (long long)cam.resolution.y >= (1ll << 24)) { error = "RES too large (W * H must be below 2^24)"; return -2; }
+    // the image is 12 B per pixel on host and device and pixel offsets are 32-bit (samples per launch narrows this to 2^24 pixels:
+    // pixelIndex then shares its word with the sample plane, checked in ptk_pathtrace_init)
+    if ((long long)cam.resolution.x * (long long)cam.resolution.y > (1ll << 29)) { error = "RES too large (W * H must not exceed 2^29)"; return -2; }
     const float yscaled = std::tan(fovy * (kPi / 180));                 // FOVY is used as a HALF angle
     const float xscaled = (yscaled * cam.resolution.x) / cam.resolution.y;
     const float fovx = (std::atan(xscaled) * 180) / kPi;

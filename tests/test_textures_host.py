@@ -105,4 +105,4 @@ def test_corrupt_headers_are_rejected_not_allocated(ptk, tmp_path):
         ptk.Scene(str(f))
     assert "RES too large" in str(e.value)
     with pytest.raises(ptk.PtkError):                       # the override path goes through the same check
-        ptk.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(5000, 5000))
+        ptk.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(50000, 50000))
