@@ -38,3 +38,19 @@ def orc():
 @pytest.fixture(scope="session")
 def scenes_dir():
     return os.path.join(ROOT, "scenes")
+
+
+def host_threads():
+    """CPU threads the oracle may really use here: the affinity mask cut by the cgroup quota (a GPU box shows every core of the host but
+    grants 16), never more than 16 — oversubscribed OpenMP loops are far slower than undersubscribed ones."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        tok = open("/sys/fs/cgroup/cpu.max").read().split()
+        if tok[0] != "max":
+            n = min(n, max(1, int(int(tok[0]) / int(tok[1]))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))

@@ -16,6 +16,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import host_threads
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NPZ = os.path.join(ROOT, "tests", "golden", "gallery_mis_test2.npz")
@@ -48,7 +49,7 @@ def gallery_oracle(orc):
     orc.L.orc_set_debug_slot_shift.argtypes = [orc.ci]
     orc.L.orc_set_sample2d_order.argtypes = [orc.ci]
     orc.set_trig_mode(orc.TRIG_LIBM)
-    orc.set_threads(os.cpu_count() or 1)
+    orc.set_threads(host_threads())
     yield orc
     orc.L.orc_set_debug_slot_shift(0)
     orc.L.orc_set_sample2d_order(1)
@@ -173,7 +174,7 @@ def test_gpu_gallery_20spp(ptk, orc, name):
     host = save_transform(img, 20)
     assert np.abs(host.astype(np.int32) - out.astype(np.int32)).max() <= 1
     # and the radiance itself is the oracle's, bit for bit (ptk trig), at the gallery's own size
-    orc.set_trig_mode(orc.TRIG_PTK); orc.set_threads(os.cpu_count() or 1)
+    orc.set_trig_mode(orc.TRIG_PTK); orc.set_threads(host_threads())
     try:
         s = orc.Scene(SCENE)
         ref = np.zeros((W * W, 3), np.float32)

@@ -15,6 +15,7 @@ import sys
 
 import numpy as np
 import pytest
+from conftest import host_threads
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +39,7 @@ def _blocks(img, W, H, b=8):
 @pytest.mark.parametrize("scene,W,H,depth,mode", [("cornell.txt", 800, 800, 8, 0), ("mis_test.txt", 512, 512, 8, 2), ("bunny_cornell.txt", 400, 400, 6, 0)])
 def test_contracted_flavour_within_stated_tolerance(tmp_path, orc, scene, W, H, depth, mode):
     d = _child(tmp_path, "fma", scene, W, H, depth, mode, "1,64")
-    orc.set_trig_mode(orc.TRIG_PTK); orc.set_threads(os.cpu_count() or 1)
+    orc.set_trig_mode(orc.TRIG_PTK); orc.set_threads(host_threads())
     try:
         o = orc.Scene(os.path.join(ROOT, "scenes", scene), res=(W, H), depth=depth)
         ref = np.zeros((o.P, 3), np.float32)

@@ -7,6 +7,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import host_threads
 
 pytestmark = pytest.mark.gpu
 
@@ -598,7 +599,7 @@ def test_frame_of_2_to_the_24_pixels(ptk, orc, torch_cuda):
     r = ptk.Renderer(s, ptk.MODE_BSDF)
     r.iterate(1)
     ref = np.zeros((o.P, 3), np.float32)
-    orc.set_threads(os.cpu_count() or 1)
+    orc.set_threads(host_threads())
     try:
         _, live = o.pathtrace(ptk.MODE_BSDF, 1, ref)
     finally:
@@ -634,7 +635,7 @@ def test_benchmarked_configuration_full_size(ptk, orc, torch_cuda):
     assert (s.width, s.height, s.trace_depth) == (800, 800, 8)
     r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes, graph=True)
     planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
-    orc.set_threads(os.cpu_count() or 1)
+    orc.set_threads(host_threads())
     try:
         for it in range(1, 7):
             r.iterate(it)
@@ -658,7 +659,7 @@ def test_configs4_tile_part_full_size(ptk, orc, torch_cuda):
     r.iterate(1)
     img = r.image(); counts, _ = r.live_counts(); r.close()
     planes = np.zeros((1, o.P, 3), np.float32)
-    orc.set_threads(os.cpu_count() or 1)
+    orc.set_threads(host_threads())
     try:
         _, live = o.pathtrace_batch(ptk.MODE_BSDF, 1, 1, planes, partition=part)
     finally:
