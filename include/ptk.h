@@ -218,7 +218,9 @@ int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
 /* Pipeline selection (A/B comparisons; all produce identical results):
- *   0 = default (10 = the same, explicitly).  One launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d for the
+ *   0 = default: 10 for scenes without triangles, 8 for scenes with (a BVH stage behind every launch leaves the fusion nothing to win:
+ *       measured 1-3 % behind);
+ *   10 = one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d for the
  *       survivors while their new rays are still in registers (the first launch of an iteration generates the camera rays
  *       instead of shading); path state and hit record are written together at the survivor's slot in its block's window, the
  *       compacted slot of a hit path (the reference's RNG key) is hit_pref[window] + its rank among the window's hits, and the last

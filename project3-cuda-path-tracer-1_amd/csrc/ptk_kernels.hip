@@ -27,6 +27,7 @@
 using namespace ptk;
 
 #define PTK_BLOCK 256
+#define PTK_SEG_GROUP 32          // blocks per first-level done counter (segments_tail)
 #define PTK_WAVES (PTK_BLOCK / 64)
 
 // Diagnostic build only (make EXTRA_HIPFLAGS=-DPTK_PHASE_TIMING, tools/diag/phase_timing.py): where a wave of k_intersect /
@@ -661,12 +662,15 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
 
 // k_finalize of the fused pipeline: slots are physical, every slot of the windows [0, ceil(n / 256)) carries valid = -2 (empty) / 0 / 1 /
 // PTK_VALID_TRI; writes the hit rank of every slot (hr: >= 0 rank among the hits of its window, -1 miss, -2 empty) and the window's
-// hit count, from which k_hit_prefix builds hit_pref (a triangle hit changes the ranks the shading keys are made of).
+// hit count, from which its last block builds hit_pref (a triangle hit changes the ranks the shading keys are made of).
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits, const int* __restrict__ valid,
-                                                          int* __restrict__ hr, int* __restrict__ agg_h) {
+                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
-    if (b * PTK_BLOCK >= n) return;
+    if (b * PTK_BLOCK >= n) {
+        if (n <= 0 && b == 0 && threadIdx.x < 8) hit_pref[threadIdx.x] = 0;
+        return;
+    }
     const int i = b * PTK_BLOCK + threadIdx.x;
     const int flag = valid[i];
     if (flag == PTK_VALID_TRI) {
@@ -680,11 +684,23 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
     int total;
     const int rank = block_excl_prefix(flag >= 1 ? 1 : 0, total);
     hr[i] = flag >= 1 ? rank : (flag == 0 ? -1 : -2);
-    if (threadIdx.x == 0) agg_h[b] = total;
-}
-__global__ void __launch_bounds__(1024) k_hit_prefix(int n_arg, const int* __restrict__ d_n, const int* __restrict__ agg_h, int* __restrict__ hit_pref) {
-    const int n = d_n ? *d_n : n_arg;
-    (void)prefix_block<1024, false>(n > 0 ? (n + PTK_BLOCK - 1) / PTK_BLOCK : 0, agg_h, hit_pref);
+    // the last block to get here builds hit_pref (two-level done counters as in segments_tail; they are back at zero after every launch)
+    __shared__ int s_last;
+    const int nb = (n + PTK_BLOCK - 1) / PTK_BLOCK, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(agg_h + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int grp = b / PTK_SEG_GROUP;
+        const int gsize = min(PTK_SEG_GROUP, nb - grp * PTK_SEG_GROUP);
+        int last = 0;
+        if (__hip_atomic_fetch_add(done + 32 * (grp + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1)
+            last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int k = threadIdx.x; k <= ng; k += PTK_BLOCK) __hip_atomic_store(done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)prefix_block<PTK_BLOCK, true>(nb, agg_h, hit_pref);
 }
 // environment map on a miss, fused pipeline: slot g of the traced stream missed iff hr[g] == -1
 __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths, const int* __restrict__ hr,
@@ -929,7 +945,6 @@ __device__ __forceinline__ void segments_block(int n_prev, const int* __restrict
 // last block of every group adds to — because agent-scope atomics on ONE word serialise at ~11 ns each: 2 500 blocks on a
 // single counter cost +17 us per launch (measured), 32 per counter in parallel ~0.4 us.  The last block also clears the
 // counters for the next launch.
-#define PTK_SEG_GROUP 32
 struct SegTail { int* done; int* pref; int* first; int* count_out; int* iter_advance; int iter_stride; };
 template <int NT>
 __device__ __forceinline__ void segments_tail(const SegTail& T, int n, int b, int total, int* __restrict__ agg_b) {
@@ -1869,9 +1884,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
         else if (wide) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
-        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h);
-        if ((rc = launch_rc())) { mark(1, false); return rc; }
-        k_hit_prefix<<<1, 1024, 0, st>>>(n_bound, d_n, ws.agg_h, ws.hit_pref);
+        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref);
         mark(1, false);
         if ((rc = launch_rc())) return rc;
     }

@@ -144,15 +144,16 @@ def test_textured_scene(ptk, orc, torch_cuda, tmp_path, mode, env):
     assert ref1.sum() > 0
     s = ptk.Scene(path); o = orc.Scene(path)
     lanes = 2
-    r = ptk.Renderer(s, m, in_flight=lanes)
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
-    for it in (1, 2, 3, 4):
-        r.iterate(it)
-        _, live = o.pathtrace(m, it, planes[(it - 1) % lanes])
-        counts, _ = r.live_counts()
-        assert np.array_equal(counts, live), (it, counts, live)
-    img = r.image(); r.close()
-    assert np.array_equal(img, planes[0] + planes[1])
+    for pipeline in (0, 10):             # the staged kernels (default with triangles) and the fused launches + k_env_miss2
+        r = ptk.Renderer(s, m, in_flight=lanes, pipeline=pipeline)
+        planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+        for it in (1, 2, 3, 4):
+            r.iterate(it)
+            _, live = o.pathtrace(m, it, planes[(it - 1) % lanes])
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, live), (pipeline, it, counts, live)
+        img = r.image(); r.close()
+        assert np.array_equal(img, planes[0] + planes[1]), pipeline
     assert np.array_equal(planes[0] if False else _first_iteration(o, m), ref1)
 
 
@@ -191,8 +192,8 @@ def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
     4 = staged intersect + shading that compacts its survivors through one chained scan, 5 = default pipeline with the work-list
     rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree with four lanes per ray, 7 / 8 = default pipeline with the
     window bookkeeping in a separate k_segments launch / in the shading kernel's last block, 9 = every bounce at full width (no k_tail),
-    10 = the default, explicitly: one fused shade + trace launch per bounce; 7 / 8 are the staged kernels that were the default until
-    round 3) produce exactly the oracle's results."""
+    10 = one fused shade + trace launch per bounce, the default for triangle-free scenes; 7 / 8 are the staged kernels, the default for
+    scenes with triangles) produce exactly the oracle's results."""
     for name, res, depth, mode in (("bunny_cornell.txt", (128, 128), 5, "MIS"), ("obj_test.txt", (64, 64), 4, "BSDF"), ("cornell.txt", (96, 96), 4, "BSDF")):
         m = MODES[mode]
         s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
@@ -214,7 +215,7 @@ def test_wide_walk_equals_threaded_walk_full_size(ptk, torch_cuda, name, mode):
     threaded walk (pipeline 5) give the same radiance and live counts bit for bit, with one and with three iterations in
     flight (the default picks between them by that number); the oracle comparison at this size is test_full_size_configs."""
     out = {}
-    for pipeline in (5, 6):
+    for pipeline in (5, 6, 10):
         for lanes in (1, 3):
             s = ptk.Scene(os.path.join(SC, name))
             r = ptk.Renderer(s, MODES[mode], pipeline=pipeline, in_flight=lanes, graph=lanes > 1)
@@ -226,12 +227,26 @@ def test_wide_walk_equals_threaded_walk_full_size(ptk, torch_cuda, name, mode):
     for lanes in (1, 3):
         assert np.array_equal(out[(5, lanes)][1], out[(6, lanes)][1])
         assert np.array_equal(out[(5, lanes)][0], out[(6, lanes)][0]), int((out[(5, lanes)][0] != out[(6, lanes)][0]).any(axis=1).sum())
+        # pipeline 10: the fused shade + trace launches with the BVH stage on the survivors' physical slots (the default picks the staged
+        # kernels for scenes with triangles, so the fused form is exercised here at full size)
+        assert np.array_equal(out[(10, lanes)][1], out[(6, lanes)][1])
+        assert np.array_equal(out[(10, lanes)][0], out[(6, lanes)][0]), int((out[(10, lanes)][0] != out[(6, lanes)][0]).any(axis=1).sum())
 
 
 @pytest.mark.parametrize("name,res,depth,mode,lanes", [("mis_test.txt", (512, 512), 16, "MIS", 1), ("mis_test.txt", (512, 512), 16, "BSDF", 3),
                                                        ("mis_test2.txt", (256, 256), 12, "DIRECT", 1), ("bunny_cornell.txt", (40, 40), 10, "MIS", 1),
                                                        ("cornell.txt", (24, 24), 8, "BSDF", 3)])
 def test_sparse_tail(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
+    _sparse_tail(ptk, orc, name, res, depth, mode, lanes, 0)
+
+
+@pytest.mark.parametrize("name,res,depth,mode,lanes", [("bunny_cornell.txt", (40, 40), 10, "MIS", 1), ("bunny_cornell.txt", (64, 64), 8, "BSDF", 3)])
+def test_sparse_tail_fused_with_triangles(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
+    """the same through pipeline 10: k_tail starting from the hits the last fused launch + BVH stage traced"""
+    _sparse_tail(ptk, orc, name, res, depth, mode, lanes, 10)
+
+
+def _sparse_tail(ptk, orc, name, res, depth, mode, lanes, pipeline):
     """k_tail: once earlier iterations have shown that only a few paths survive a bounce, the rest of every iteration runs in one
     single-workgroup launch.  The switch happens a few iterations in (asynchronous read-back of the live counts), so twelve
     iterations cover both regimes; tiny frames put whole iterations in the tail (also with the BVH walk and shadow rays in it).
@@ -239,7 +254,7 @@ def test_sparse_tail(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
     m = MODES[mode]
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
-    r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
+    r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1, pipeline=pipeline)
     planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
     rays = 0
     for it in range(1, 13):

@@ -17,7 +17,7 @@ KERNELS = (("k_intersect<false, false>", "k_intersect"), ("k_intersect<false, tr
            # the fused default pipeline (round 3)
            ("k_shade_trace<0, false, false>", "k_shade_trace"), ("k_shade_trace<0, true, false>", "k_shade_trace_gen"),
            ("k_shade_trace<0, false, true>", "k_shade_trace_split"), ("k_shade_trace<0, true, true>", "k_shade_trace_gen_split"),
-           ("k_finalize2", "k_finalize2"), ("k_hit_prefix", "k_hit_prefix"))
+           ("k_finalize2", "k_finalize2"))
 
 
 def per_dispatch(path, kernel_prefix):
