@@ -750,6 +750,44 @@ def _many_primitives_scene(path, n_geoms, seed):
         f.write("\n".join(L) + "\n")
 
 
+@pytest.mark.parametrize("n_mats,mode", [(15, "BSDF"), (17, "MIS"), (40, "BSDF"), (70, "MIS")])
+def test_many_materials(ptk, orc, torch_cuda, tmp_path, n_mats, mode):
+    """Both sides of the material tables the shading kernels stage in LDS (16 records in the fused k_shade_trace, 64 in the staged
+    k_shade_binned; the rest come from global memory): a room with n_mats small primitives, each with a material of its own (all five
+    types, random parameters).  Fused launches (10) and staged kernels (8) == oracle, bit for bit."""
+    rng = np.random.default_rng(100 + n_mats)
+    L = ["MATERIAL light", "TYPE Light", "ALBEDO 8 8 8", "", "MATERIAL white", "TYPE Lambertian", "ALBEDO 0.8 0.8 0.8", ""]
+    types = ["Lambertian", "MetallicWorkflow", "Dielectric", "Microfacet", "Light"]
+    for k in range(n_mats):
+        t = types[k % 4] if k % 9 else "Light"
+        a = rng.uniform(0.2, 0.95, 3) if t != "Light" else rng.uniform(1, 4, 3)
+        L += [f"MATERIAL m{k}", f"TYPE {t}", "ALBEDO %.4f %.4f %.4f" % tuple(a), "METALLIC %.3f" % rng.uniform(0, 1), "ROUGHNESS %.3f" % rng.uniform(0.05, 0.9),
+              "IOR %.3f" % rng.uniform(1.2, 1.8), ""]
+    L += ["CAMERA", "RES 96 96", "FOVY 25", "ITERATIONS 4", "DEPTH 6", "FILE mats", "EYE 0 5 14", "LOOKAT 0 5 0", "UP 0 1 0", ""]
+    objs = [("sphere", "light", (0, 9, 0), (2, 2, 2)), ("cube", "white", (0, 0, 0), (12, 0.02, 12)), ("cube", "white", (0, 10, 0), (12, 0.02, 12)),
+            ("cube", "white", (-6, 5, 0), (0.02, 10, 12)), ("cube", "white", (6, 5, 0), (0.02, 10, 12)), ("cube", "white", (0, 5, -6), (12, 10, 0.02))]
+    for k in range(n_mats):
+        kind = "cube" if k % 2 else "sphere"
+        objs.append((kind, f"m{k}", tuple(rng.uniform([-4.5, 1, -4.5], [4.5, 8.5, 3])), tuple(np.repeat(rng.uniform(0.6, 1.4), 3))))
+    for i, (kind, mat, pos, sc) in enumerate(objs):
+        L += [f"OBJECT o{i}", kind, f"material {mat}", "TRANS %.6g %.6g %.6g" % pos, "ROTAT 0 %d 0" % (17 * i % 90), "SCALE %.6g %.6g %.6g" % sc, ""]
+    path = tmp_path / f"mats{n_mats}.txt"; path.write_text("\n".join(L) + "\n")
+    m = MODES[mode]
+    o = orc.Scene(str(path))
+    assert o.n_materials == n_mats + 2
+    ref = np.zeros((o.P, 3), np.float32)
+    lives = [o.pathtrace(m, it, ref)[1] for it in (1, 2, 3)]
+    assert ref.sum() > 0
+    for pipeline in (10, 8):
+        s = ptk.Scene(str(path))
+        r = ptk.Renderer(s, m, pipeline=pipeline)
+        for k, it in enumerate((1, 2, 3)):
+            r.iterate(it)
+            assert np.array_equal(r.live_counts()[0], lives[k]), (pipeline, it)
+        img = r.image(); r.close(); s.close()
+        assert np.array_equal(img, ref), (pipeline, int((img != ref).any(axis=1).sum()))
+
+
 @pytest.mark.parametrize("n_geoms,mode", [(70, "MIS"), (33, "BSDF"), (140, "DIRECT"), (512, "BSDF"), (513, "MIS")])
 def test_many_primitives(ptk, orc, torch_cuda, tmp_path, n_geoms, mode):
     """More analytic primitives than one 32-wide candidate chunk, rotated and overlapping: images and live counts == oracle,
