@@ -188,7 +188,14 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
     s_best[tid] = ~0ull;
     for (int base = 0; base < S.n_geoms; base += 32) {
         const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
+#ifdef PTK_DIAG_DOUBLE_CAND      // timing experiments only (tools/diag): the section runs twice on laundered inputs, same results
+        f3 ro2 = ro; asm volatile("" : "+v"(ro2.x), "+v"(ro2.y), "+v"(ro2.z));
+        const Cand call0 = analytic_candidates(S, base, n, ro2, rd);
+        Cand call = analytic_candidates(S, base, n, ro, rd);
+        call.cube |= call0.cube & 0u; asm volatile("" :: "v"(call0.cube), "v"(call0.sphere));
+#else
         const Cand call = analytic_candidates(S, base, n, ro, rd);
+#endif
         for (int half = 0; half * LP < n; ++half) {       // the pair list holds LP primitives x NT rays
             Cand c = call;
             const unsigned hm = ((1u << LP) - 1u) << (LP * half);
@@ -225,6 +232,11 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
                     const float4 o4 = s_ray[2 * r], d4 = s_ray[2 * r + 1];
                     const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
                     const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
+#ifdef PTK_DIAG_DOUBLE_TEST      // timing experiments only
+                    { f3 po2 = po; asm volatile("" : "+v"(po2.x), "+v"(po2.y), "+v"(po2.z)); f3 P2 = mk3(0, 0, 0), N2 = mk3(0, 0, 0);
+                      const float t2 = pi < Tc ? box_test(g, po2, pd, P2, N2) : sphere_test(g, po2, pd, P2, N2);
+                      asm volatile("" :: "v"(t2), "v"(P2.x), "v"(P2.y), "v"(P2.z), "v"(N2.x), "v"(N2.y), "v"(N2.z)); }
+#endif
                     const float t = pi < Tc ? box_test(g, po, pd, P, NSv) : sphere_test(g, po, pd, P, NSv);
                     if (t > 0.0f && FLT_MAX > t) {
                         key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)(base + k);
@@ -789,6 +801,10 @@ __device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& g
         return 0;
     }
     Scatter s;
+#ifdef PTK_DIAG_DOUBLE_SCATTER   // timing experiments only
+    { Rng rng2 = rng; f3 n2 = h.n; asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z)); Scatter s2; scatter_sample(m, n2, p.d, s2, rng2);
+      asm volatile("" :: "v"(s2.pdf), "v"(s2.dir.x), "v"(s2.dir.y), "v"(s2.dir.z), "v"(s2.bsdf.x), "v"(s2.bsdf.y), "v"(s2.bsdf.z)); }
+#endif
     scatter_sample(m, h.n, p.d, s, rng);
     if (s.pdf == 0) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
     if (m.type == PTK_MAT_LIGHT) {
@@ -1193,7 +1209,12 @@ __device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, con
     return (w0 + k) * PTK_BLOCK + (i - base);
 }
 
-template <int MODE, bool GEN, bool SPLIT>
+// COMPACT (triangle-free scenes without textures, BSDF / DIRECT modes): 64 B per path instead of 84.  Shading never reads the ray origin or
+// prevPdf outside MIS (lightPDF, pathtrace.cu:547-554) nor the hit distance beyond its sign, and (uv, geomID, triangleID) only with textures
+// or MIS — so the four 16-byte streams are  paths.o_pix = (direction, pixelIndex), paths.d_bnc = (color, remainingBounces),
+// hits.t_n = (normal, hit rank: the `hr` word), hits.p_mat = (point, materialId); col_pdf, uv_ids and the hr array stay untouched.
+// The timed configuration is partly bound by HBM traffic (+32 B per path costs 5.7 %, measured): −24 % bytes per path-bounce.
+template <int MODE, bool GEN, bool SPLIT, bool COMPACT>
 #ifndef PTK_FUSED_WAVES_BSDF
 #define PTK_FUSED_WAVES_BSDF 7
 #endif
@@ -1252,9 +1273,14 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             const float fx = static_cast<float>(static_cast<float>(x) + ((double)r.x - 0.5) - gen.cam.W * 0.5f);
             const float fy = static_cast<float>(static_cast<float>(y) + ((double)r.y - 0.5) - gen.cam.H * 0.5f);
             const f3 d = normalize(gen.cam.view - gen.cam.right * gen.cam.plx * fx - gen.cam.up * gen.cam.ply * fy);
-            st4(io.nxt.o_pix, i, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, __int_as_float((sidx << 24) | (x + y * gen.cam.W))));
-            st4(io.nxt.d_bnc, i, make_float4(d.x, d.y, d.z, __int_as_float(gen.trace_depth)));
-            st4(io.nxt.col_pdf, i, make_float4(1.f, 1.f, 1.f, -1.f));
+            if (COMPACT) {
+                st4(io.nxt.o_pix, i, make_float4(d.x, d.y, d.z, __int_as_float((sidx << 24) | (x + y * gen.cam.W))));
+                st4(io.nxt.d_bnc, i, make_float4(1.f, 1.f, 1.f, __int_as_float(gen.trace_depth)));
+            } else {
+                st4(io.nxt.o_pix, i, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, __int_as_float((sidx << 24) | (x + y * gen.cam.W))));
+                st4(io.nxt.d_bnc, i, make_float4(d.x, d.y, d.z, __int_as_float(gen.trace_depth)));
+                st4(io.nxt.col_pdf, i, make_float4(1.f, 1.f, 1.f, -1.f));
+            }
             s_ray[2 * tid] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
             s_ray[2 * tid + 1] = make_float4(d.x, d.y, d.z, 0.f);
         }
@@ -1264,12 +1290,17 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
         int hit_base = 0;
         const int src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, hit_base);      // 0 for i >= n
-        const int hr = (i < n) ? io.hr_cur[src_mine] : -1;
-        const int flag = hr >= 0;
+        // COMPACT: one word per path at the head — rank among the window's hits | material type << 8 (the sort key), -1 for a miss
+        const int hr_word = (i < n) ? (COMPACT ? __float_as_int(io.hcur.t_n[4 * (size_t)src_mine + 3]) : io.hr_cur[src_mine]) : -1;
+        const int flag = hr_word >= 0;
+        const int hr = COMPACT ? (hr_word & 0xff) : hr_word;
         s_src[tid] = src_mine;
-        const int mat_word = (i < n) ? __float_as_int(io.hcur.p_mat[4 * (size_t)src_mine + 3]) : 0;      // stale for a miss: unused then
         int key = NKEY - 1;
-        if (flag) key = fetch_material_type(S, mt, mat_word);
+        if (COMPACT) { if (flag) key = hr_word >> 8; }
+        else {
+            const int mat_word = (i < n) ? __float_as_int(io.hcur.p_mat[4 * (size_t)src_mine + 3]) : 0;      // stale for a miss: unused then
+            if (flag) key = fetch_material_type(S, mt, mat_word);
+        }
         unsigned long long bal[NKEY];
 #pragma unroll
         for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
@@ -1295,15 +1326,28 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             src = s_perm[tid];
             const int slot = s_slot[src];
             const int ps = s_src[src];
-            const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps);
-            const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(io.hcur.uv_ids, ps);
-            const float4 o4 = ld4(io.cur.o_pix, ps), d4 = ld4(io.cur.d_bnc, ps), c4 = ld4(io.cur.col_pdf, ps);
             Hit h;
-            h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
-            h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
-            p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
-            p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
-            p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+            if (COMPACT) {
+                const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps);
+                const float4 a4 = ld4(io.cur.o_pix, ps), b4 = ld4(io.cur.d_bnc, ps);
+                h.t = 1.0f; h.n = mk3(h0.x, h0.y, h0.z); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+                h.uv.x = 0.f; h.uv.y = 0.f; h.geom = -1; h.tri = -1;
+                p.o = mk3(0, 0, 0); p.pix = __float_as_int(a4.w);
+                p.d = mk3(a4.x, a4.y, a4.z); p.bounces = __float_as_int(b4.w);
+                p.col = mk3(b4.x, b4.y, b4.z); p.prevPdf = -1.f;
+            } else {
+                const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps);
+                const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(io.hcur.uv_ids, ps);
+                const float4 o4 = ld4(io.cur.o_pix, ps), d4 = ld4(io.cur.d_bnc, ps), c4 = ld4(io.cur.col_pdf, ps);
+#ifdef PTK_DIAG_EXTRA_TRAFFIC    // timing experiments only: +16 B read and +16 B written per path (the unused third of the slim hit record)
+                { const float4 x4 = ld4(io.hcur.uv_ids, ps); asm volatile("" :: "v"(x4.x), "v"(x4.y), "v"(x4.z), "v"(x4.w)); }
+#endif
+                h.t = h0.x; h.n = mk3(h0.y, h0.z, h0.w); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+                h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
+                p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+                p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+                p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+            }
             alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
         }
         __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
@@ -1323,9 +1367,14 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         if (alive) {
             my_rank = s_perm[src];
             const int s2 = b * NT + my_rank;
-            st4(io.nxt.o_pix, s2, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
-            st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
-            st4(io.nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+            if (COMPACT) {
+                st4(io.nxt.o_pix, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.pix)));
+                st4(io.nxt.d_bnc, s2, make_float4(p.col.x, p.col.y, p.col.z, __int_as_float(p.bounces)));
+            } else {
+                st4(io.nxt.o_pix, s2, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+                st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+                st4(io.nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+            }
             s_ray[2 * my_rank] = make_float4(p.o.x, p.o.y, p.o.z, 0.f);          // hand the new ray to the thread that traces it
             s_ray[2 * my_rank + 1] = make_float4(p.d.x, p.d.y, p.d.z, 0.f);
         }
@@ -1343,21 +1392,31 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         int flag = 0;
         bool heavy = false;
         const int slot = b * NT + tid;
+        Hit h;
+        h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
         if (active) {
-            Hit h;
             flag = a.geom >= 0;
             if (flag) { if (gs.on) analytic_record_staged(gs.xf, a, h); else analytic_record(S, a, h); }
+#ifdef PTK_DIAG_DOUBLE_RECORD    // timing experiments only
+            if (flag && gs.on) { Analytic a2 = a; asm volatile("" : "+v"(a2.NS.x), "+v"(a2.NS.y), "+v"(a2.NS.z)); Hit h2; analytic_record_staged(gs.xf, a2, h2);
+                                 asm volatile("" :: "v"(h2.n.x), "v"(h2.n.y), "v"(h2.n.z)); }
+#endif
             if (SPLIT) {                       // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
                 const DevNode root = S.nodes[(size_t)mtbvh_dir(rd) * S.bvh_size];
                 float tEnter;
                 heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
             }
-            if (flag) {
-                st4(io.hnxt.t_n, slot, make_float4(h.t, h.n.x, h.n.y, h.n.z));
-                st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
-                if (!S.slim_hits) st4(io.hnxt.uv_ids, slot, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
-            } else {
-                st4(io.hnxt.t_n, slot, make_float4(-1.f, 0.f, 0.f, 0.f));
+            if (!COMPACT) {
+#ifdef PTK_DIAG_EXTRA_TRAFFIC
+                st4(io.hnxt.uv_ids, slot, make_float4(ro.x, ro.y, rd.x, rd.y));
+#endif
+                if (flag) {
+                    st4(io.hnxt.t_n, slot, make_float4(h.t, h.n.x, h.n.y, h.n.z));
+                    st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+                    if (!S.slim_hits) st4(io.hnxt.uv_ids, slot, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
+                } else {
+                    st4(io.hnxt.t_n, slot, make_float4(-1.f, 0.f, 0.f, 0.f));
+                }
             }
         }
         const unsigned long long hb = __ballot(flag != 0);
@@ -1374,13 +1433,20 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             if (lane == 0) s_red[wid] = __popcll(vb);
             __syncthreads();
             if (tid == 0) { int t = 0; for (int w = 0; w < NW; ++w) t += s_red[w]; io.heavy_agg[b] = t; }
+        } else if (COMPACT) {
+            // hit record with the rank in the normal's spare word: only the slots of survivors are written (nobody reads the others)
+            if (active) {
+                const int word = flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1;      // rank < 256; the type is the next launch's sort key
+                st4(io.hnxt.t_n, slot, make_float4(h.n.x, h.n.y, h.n.z, __int_as_float(word)));
+                if (flag) st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+            }
         } else {
             io.hr_nxt[slot] = active ? (flag ? before + __popcll(hb & lt) : -1) : -2;
         }
     } else if (SPLIT) {
         io.valid_nxt[b * NT + tid] = -2; io.heavy_flag[b * NT + tid] = 0;
         if (tid == 0) io.heavy_agg[b] = 0;
-    } else {
+    } else if (!COMPACT) {
         io.hr_nxt[b * NT + tid] = -2;
     }
     segments_tail2<NT>(tail, n, b, total, hits, io.agg_s, SPLIT ? nullptr : io.agg_h);
@@ -1461,6 +1527,7 @@ struct TailArgs {
     int* iter_advance; int iter_stride;
     // fused pipeline: bounce depth0 has been traced already (k_shade_trace); its hit records / ranks sit at the paths' physical slots
     PtkHits hits0; const int* hr0; int have_hits;
+    int compact;                             // ... in k_shade_trace's compact stream layout
 };
 
 template <int MODE>
@@ -1491,11 +1558,22 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
             p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
             if (i < n) {
                 const int src = gather_source(G, i / PTK_BLOCK, i, n);
+                const bool traced = A.have_hits && depth == A.depth0;      // by the last full-width launch (ENV radiance of its misses added there)
+                if (traced && A.compact) {                                  // k_shade_trace's compact streams: (d, pix) (col, bounces) (n, rank) (p, mat)
+                    const float4 a4 = ld4(cur.o_pix, src), b4 = ld4(cur.d_bnc, src), h0 = ld4(A.hits0.t_n, src);
+                    p.pix = __float_as_int(a4.w); p.d = mk3(a4.x, a4.y, a4.z); p.bounces = __float_as_int(b4.w);
+                    p.col = mk3(b4.x, b4.y, b4.z); p.prevPdf = -1.f;
+                    flag = __float_as_int(h0.w) >= 0;
+                    if (flag) {
+                        const float4 h1 = ld4(A.hits0.p_mat, src);
+                        h.t = 1.0f; h.n = mk3(h0.x, h0.y, h0.z); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+                    }
+                } else {
                 const float4 o4 = ld4(cur.o_pix, src), d4 = ld4(cur.d_bnc, src), c4 = ld4(cur.col_pdf, src);
                 p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
                 p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
                 p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
-                if (A.have_hits && depth == A.depth0) {             // traced by the last full-width launch (ENV radiance of its misses added there)
+                if (traced) {
                     flag = A.hr0[src] >= 0;
                     if (flag) {
                         const float4 h0 = ld4(A.hits0.t_n, src), h1 = ld4(A.hits0.p_mat, src);
@@ -1506,6 +1584,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
                 } else {
                     flag = closest_hit<false>(S, gs, p.o, p.d, h, nv, nt);
                     if (!flag && S.env_tex >= 0) add_radiance(img, p.pix, nan_to_zero(p.col * env_radiance(S, p.d)));   // pathtrace.cu:303-311
+                }
                 }
             }
             int total;
@@ -1823,13 +1902,16 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
 // fused pipeline: one launch shades bounce dt - 1 (paths / hits / ranks of `cur`) — or, gen, generates the camera rays — and traces
 // bounce dt into `nxt`.  Scenes with triangles continue with the work-list BVH stage on the survivors' physical slots.
 template <int MODE, bool GEN>
-static int launch_shade_trace_t(const SceneView& S, bool split, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
+static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
                                 const TraceIO& io, float* img, unsigned plane_stride, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
     const int g = grid_for(capacity);
-    if (split) k_shade_trace<MODE, GEN, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
-    else k_shade_trace<MODE, GEN, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    else if (compact && MODE != PTK_MODE_MIS) k_shade_trace<MODE, GEN, false, (MODE != PTK_MODE_MIS)><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     return launch_rc();
 }
+// the fused pipeline's compact stream layout (k_shade_trace): no triangles, no textures, no MIS
+bool trace_compact(const SceneView& S, int mode) { return S.n_tris == 0 && S.n_tex == 0 && mode != PTK_MODE_MIS; }
 int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool)) {
@@ -1839,6 +1921,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     SceneView S = S_in;
     S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
     const bool split = S.n_tris > 0 && ws.queue && ws.list;
+    const bool compact = !split && trace_compact(S, mode);
     GenArgs G;
     G.cam.W = cam.resolution.x; G.cam.H = cam.resolution.y;
     G.cam.pos = mk3(cam.position.x, cam.position.y, cam.position.z);
@@ -1861,13 +1944,13 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     int rc;
     if (gen) {
         switch (mode) {                 // (the mode only matters for the hit-record layout the next launch expects: same kernel body)
-        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
         }
     } else {
         switch (mode) {
-        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
-        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
         default: rc = PTK_E_BADARG;
         }
     }
@@ -1900,6 +1983,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     SceneView S = S_in;
     TailArgs A;
     A.have_hits = hits0 != nullptr ? 1 : 0;
+    A.compact = (hits0 != nullptr && S_in.n_tris == 0 && trace_compact(S_in, mode)) ? 1 : 0;
     A.hits0 = hits0 ? *hits0 : PtkHits{nullptr, nullptr, nullptr}; A.hr0 = hr0;
     if (hits0) S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;      // as the launch that wrote them
     A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth0 = depth0; A.trace_depth = trace_depth;
