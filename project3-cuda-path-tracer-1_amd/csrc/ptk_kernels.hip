@@ -1290,13 +1290,16 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
         int hit_base = 0;
         const int src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, hit_base);      // 0 for i >= n
-        // COMPACT: one word per path at the head — rank among the window's hits | material type << 8 (the sort key), -1 for a miss
+        // one word per path at the head — rank among the window's hits | material type << 8 (the sort key), -1 for a miss: in the normal's
+        // spare word (COMPACT) or in the hr array.  (Reading the material id from the hit record here, a second strided stream ahead of
+        // the sort, cost 12 % of the headline.)
         const int hr_word = (i < n) ? (COMPACT ? __float_as_int(io.hcur.t_n[4 * (size_t)src_mine + 3]) : io.hr_cur[src_mine]) : -1;
         const int flag = hr_word >= 0;
-        const int hr = COMPACT ? (hr_word & 0xff) : hr_word;
+        // (SPLIT: k_finalize2 writes plain ranks — a triangle hit's material is only known there — and the type comes from the hit record)
+        const int hr = SPLIT ? hr_word : (hr_word & 0xff);
         s_src[tid] = src_mine;
         int key = NKEY - 1;
-        if (COMPACT) { if (flag) key = hr_word >> 8; }
+        if (!SPLIT) { if (flag) key = hr_word >> 8; }
         else {
             const int mat_word = (i < n) ? __float_as_int(io.hcur.p_mat[4 * (size_t)src_mine + 3]) : 0;      // stale for a miss: unused then
             if (flag) key = fetch_material_type(S, mt, mat_word);
@@ -1441,7 +1444,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
                 if (flag) st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
             }
         } else {
-            io.hr_nxt[slot] = active ? (flag ? before + __popcll(hb & lt) : -1) : -2;
+            io.hr_nxt[slot] = active ? (flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1) : -2;
         }
     } else if (SPLIT) {
         io.valid_nxt[b * NT + tid] = -2; io.heavy_flag[b * NT + tid] = 0;
