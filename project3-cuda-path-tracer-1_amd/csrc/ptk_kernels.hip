@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
     }
     const int i = b * PTK_BLOCK + threadIdx.x;
     const int flag = valid[i];
+    int mat = 0;
     if (flag == PTK_VALID_TRI) {
         const float4 r = ld4(hits.uv_ids, i);
         Hit h;
@@ -692,10 +693,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
         st4(hits.t_n, i, make_float4(h.t, h.n.x, h.n.y, h.n.z));
         st4(hits.p_mat, i, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
         if (!S.slim_hits) st4(hits.uv_ids, i, make_float4(h.uv.x, h.uv.y, __int_as_float(h.geom), __int_as_float(h.tri)));
-    }
+        mat = h.mat;
+    } else if (flag == 1) mat = __float_as_int(hits.p_mat[4 * (size_t)i + 3]);      // analytic winner: record written by k_shade_trace
     int total;
     const int rank = block_excl_prefix(flag >= 1 ? 1 : 0, total);
-    hr[i] = flag >= 1 ? rank : (flag == 0 ? -1 : -2);
+    hr[i] = flag >= 1 ? (rank | (S.mats[mat].type << 8)) : (flag == 0 ? -1 : -2);      // rank | material type << 8: the next launch's head reads one word
     // the last block to get here builds hit_pref (two-level done counters as in segments_tail; they are back at zero after every launch)
     __shared__ int s_last;
     const int nb = (n + PTK_BLOCK - 1) / PTK_BLOCK, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
@@ -1295,15 +1297,11 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         // the sort, cost 12 % of the headline.)
         const int hr_word = (i < n) ? (COMPACT ? __float_as_int(io.hcur.t_n[4 * (size_t)src_mine + 3]) : io.hr_cur[src_mine]) : -1;
         const int flag = hr_word >= 0;
-        // (SPLIT: k_finalize2 writes plain ranks — a triangle hit's material is only known there — and the type comes from the hit record)
-        const int hr = SPLIT ? hr_word : (hr_word & 0xff);
+        // (SPLIT: k_finalize2 writes the word — a triangle hit's material is only known there)
+        const int hr = hr_word & 0xff;
         s_src[tid] = src_mine;
         int key = NKEY - 1;
-        if (!SPLIT) { if (flag) key = hr_word >> 8; }
-        else {
-            const int mat_word = (i < n) ? __float_as_int(io.hcur.p_mat[4 * (size_t)src_mine + 3]) : 0;      // stale for a miss: unused then
-            if (flag) key = fetch_material_type(S, mt, mat_word);
-        }
+        if (flag) key = hr_word >> 8;
         unsigned long long bal[NKEY];
 #pragma unroll
         for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
