@@ -254,7 +254,7 @@ def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
         return None
     achieved = rays_p * BYTES_PER_PATH_BOUNCE / (ms * 1e-3) / 1e9
     avg_us = 1e3 * ms / launches
-    rp = rocprof_avg_us(scene_file, "k_shade_trace<0, false, false>") if (scene.width, scene.height) == (800, 800) else None
+    rp = rocprof_avg_us(scene_file, "k_shade_trace<0, false, false") if (scene.width, scene.height) == (800, 800) else None
     pm = ((pmc_record(scene_file) or {}).get("k_shade_trace") or {}) if (scene.width, scene.height) == (800, 800) else {}
     return {"bound": "valu", "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic_bytes_per_launch"),

@@ -1168,6 +1168,60 @@ struct TraceIO {
 struct SegTail2 { int* done; int* pref; int* first; int* hit_pref; int* count_out; int* iter_advance; int iter_stride; unsigned long long* ray_total; };
 struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix; };
 
+// segments_block for the fused launches: the window prefix of the survivor counts (pref / first / next live count) AND the prefix of the hit
+// counts (hit_pref) in ONE pass — the last block of a launch runs alone, its time is on every lane's critical path (two separate scans took
+// twice the barriers).  Four consecutive windows per thread; agg_h == nullptr: no hit prefix (SPLIT: k_finalize2 builds it).
+template <int NT>
+__device__ __forceinline__ void segments_block2(int n_prev, const int* __restrict__ agg_s, const int* __restrict__ agg_h, int* __restrict__ pref, int* __restrict__ first,
+                                                int* __restrict__ hit_pref, int* __restrict__ count_out, int* iter_advance, int iter_stride) {
+    constexpr int NW = NT / 64;
+    __shared__ int s_ws[NW], s_wh[NW];
+    __shared__ int s_carry_s, s_carry_h;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nw = n_prev > 0 ? (n_prev + PTK_BLOCK - 1) / PTK_BLOCK : 0;
+    if (tid == 0) { s_carry_s = 0; s_carry_h = 0; }
+    __syncthreads();
+    for (int base = 0; base < nw; base += 4 * NT) {
+        const int idx = base + 4 * tid;
+        int cs[4] = {0, 0, 0, 0}, ch[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (idx + k < nw) {
+            cs[k] = __hip_atomic_load(agg_s + idx + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (agg_h) ch[k] = __hip_atomic_load(agg_h + idx + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int vs = (cs[0] + cs[1]) + (cs[2] + cs[3]), vh = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+        int is = vs, ih = vh;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(is, o, 64), c = __shfl_up(ih, o, 64); if (lane >= o) { is += a; ih += c; } }
+        if (lane == 63) { s_ws[wid] = is; s_wh[wid] = ih; }
+        __syncthreads();
+        int offs = 0, tots = 0, offh = 0, toth = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int a = s_ws[w], c = s_wh[w]; offs += (w < wid) ? a : 0; tots += a; offh += (w < wid) ? c : 0; toth += c; }
+        const int carry_s = s_carry_s, carry_h = s_carry_h;
+        int es = carry_s + offs + is - vs, eh = carry_h + offh + ih - vh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (idx + k < nw) {
+                pref[idx + k] = es;
+                if (agg_h) hit_pref[idx + k] = eh;
+                const int B = (es + PTK_BLOCK - 1) / PTK_BLOCK;
+                if (cs[k] > 0 && B * PTK_BLOCK < es + cs[k]) first[B] = idx + k;
+            }
+            es += cs[k]; eh += ch[k];
+        }
+        __syncthreads();
+        if (tid == 0) { s_carry_s = carry_s + tots; s_carry_h = carry_h + toth; }
+        __syncthreads();
+    }
+    const int total = s_carry_s, total_h = s_carry_h;
+    if (tid < 8) { pref[nw + tid] = total; if (agg_h) hit_pref[nw + tid] = total_h; }
+    if (tid == 0) {
+        if (count_out) *count_out = total;
+        if (iter_advance) *iter_advance += iter_stride;
+    }
+}
+
 // end of a k_shade_trace block: publish the window's survivor and hit counts; the last block of the launch builds the tables
 template <int NT>
 __device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, int survivors, int hits, int* __restrict__ agg_s, int* __restrict__ agg_h) {
@@ -1187,8 +1241,7 @@ __device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, 
     __syncthreads();
     if (!s_last) return;
     for (int k = threadIdx.x; k <= ng; k += NT) __hip_atomic_store(T.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (T.hit_pref && agg_h) (void)prefix_block<NT, true>(n > 0 ? nb : 0, agg_h, T.hit_pref);
-    segments_block<NT, true>(n, agg_s, T.pref, T.first, T.count_out, T.iter_advance, T.iter_stride);
+    segments_block2<NT>(n, agg_s, (T.hit_pref && agg_h) ? agg_h : nullptr, T.pref, T.first, T.hit_pref, T.count_out, T.iter_advance, T.iter_stride);
     if (threadIdx.x == 0 && T.ray_total) atomicAdd(T.ray_total, (unsigned long long)*T.count_out);     // rays of the bounce just traced
 }
 
@@ -1231,9 +1284,11 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
     constexpr int OVER = (MATS * (int)sizeof(DevMaterial) + 3 * NT * (int)sizeof(int)) > NT * LP * 2 ? (MATS * (int)sizeof(DevMaterial) + 3 * NT * (int)sizeof(int)) : NT * LP * 2;
     // shared by the two phases: shading = materials + permutation / slot / source tables (3 x 1 KB); tracing = pair list
     __shared__ __attribute__((aligned(16))) unsigned char s_over[OVER];
-    __shared__ float4 s_ray[2 * NT];
-    __shared__ float2 s_res[3 * NT];
-    __shared__ unsigned long long s_best[NT];
+    // the trace phase's LDS: rays (8 KB), the winners' hit points (6 KB), the ds_min keys (2 KB)
+    __shared__ float4 s_stage[4 * NT];
+    float4* s_ray = s_stage;
+    float2* s_res = reinterpret_cast<float2*>(s_stage + 2 * NT);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_stage + 2 * NT + (3 * NT) / 2);
     __shared__ int s_cnt[NW][NKEY];
     __shared__ int s_red[NW];
     __shared__ int s_tcnt[NW];
@@ -1329,8 +1384,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             const int ps = s_src[src];
             Hit h;
             if (COMPACT) {
-                const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps);
-                const float4 a4 = ld4(io.cur.o_pix, ps), b4 = ld4(io.cur.d_bnc, ps);
+                const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps), a4 = ld4(io.cur.o_pix, ps), b4 = ld4(io.cur.d_bnc, ps);
                 h.t = 1.0f; h.n = mk3(h0.x, h0.y, h0.z); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
                 h.uv.x = 0.f; h.uv.y = 0.f; h.geom = -1; h.tri = -1;
                 p.o = mk3(0, 0, 0); p.pix = __float_as_int(a4.w);
@@ -1376,8 +1430,8 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
                 st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
                 st4(io.nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
             }
-            s_ray[2 * my_rank] = make_float4(p.o.x, p.o.y, p.o.z, 0.f);          // hand the new ray to the thread that traces it
-            s_ray[2 * my_rank + 1] = make_float4(p.d.x, p.d.y, p.d.z, 0.f);
+            s_ray[2 * my_rank] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix));          // hand the new ray to the thread that traces it
+            s_ray[2 * my_rank + 1] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces));
         }
     }
     __syncthreads();                           // shading tables are dead, s_ray is complete: the pair list may overwrite s_over
@@ -1386,7 +1440,9 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
     if (total > 0) {                           // block-uniform
         const bool active = tid < total;
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
-        if (active) { const float4 o4 = s_ray[2 * tid], d4 = s_ray[2 * tid + 1]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z); }
+        if (active) {
+            const float4 o4 = s_ray[2 * tid], d4 = s_ray[2 * tid + 1]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+        }
         Analytic a;
         if (gs.on) analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
         else { a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0); if (active) analytic_closest(S, gs, ro, rd, a); }

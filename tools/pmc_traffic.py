@@ -15,8 +15,8 @@ KERNELS = (("k_intersect<false, false>", "k_intersect"), ("k_intersect<false, tr
            ("k_traverse_wide<false, 4>", "k_traverse_wide"), ("k_traverse<false>", "k_traverse"), ("k_finalize(", "k_finalize"),
            ("k_shade_binned", "k_shade_binned"), ("k_generate", "k_generate"),
            # the fused default pipeline (round 3)
-           ("k_shade_trace<0, false, false>", "k_shade_trace"), ("k_shade_trace<0, true, false>", "k_shade_trace_gen"),
-           ("k_shade_trace<0, false, true>", "k_shade_trace_split"), ("k_shade_trace<0, true, true>", "k_shade_trace_gen_split"),
+           ("k_shade_trace<0, false, false", "k_shade_trace"), ("k_shade_trace<0, true, false", "k_shade_trace_gen"),
+           ("k_shade_trace<0, false, true", "k_shade_trace_split"), ("k_shade_trace<0, true, true", "k_shade_trace_gen_split"),
            ("k_finalize2", "k_finalize2"))
 
 
