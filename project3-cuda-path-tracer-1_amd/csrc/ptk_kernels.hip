@@ -1292,6 +1292,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
     __shared__ int s_cnt[NW][NKEY];
     __shared__ int s_red[NW];
     __shared__ int s_tcnt[NW];
+    __shared__ unsigned long long s_alive[NT / 64];
     DevMaterial* s_mats = reinterpret_cast<DevMaterial*>(s_over);
     int* s_perm = reinterpret_cast<int*>(s_over + MATS * sizeof(DevMaterial));
     int* s_slot = s_perm + NT;
@@ -1310,6 +1311,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         }
         return;
     }
+    if (tid < NT / 64) s_alive[tid] = 0ull;                        // (published by the barrier in stage_geoms / stage_materials)
     const GeomStage gs = stage_geoms(S);                           // the trace phase always needs the primitives; MIS / DIRECT shading too
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1405,22 +1407,21 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             }
             alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
         }
-        __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
-        s_slot[tid] = 0;
+        // survivor rank in the ORIGINAL (dense) order — the next bounce's compacted order, hence its RNG keys: every survivor sets the bit of
+        // its original position in a 256-bit LDS mask, one barrier, rank = set bits below it (five barriers with a flag array + ballot before)
+        if (alive) atomicOr(&s_alive[src >> 6], 1ull << (src & 63));
         __syncthreads();
-        if (src >= 0) s_slot[src] = alive;
-        __syncthreads();
-        const int alive_here = s_slot[tid];
-        const unsigned long long ab = __ballot(alive_here != 0);
-        if (lane == 0) s_red[wid] = __popcll(ab);
-        __syncthreads();
-        int before = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { const int c = s_red[w]; before += (w < wid) ? c : 0; total += c; }
-        s_perm[tid] = before + __popcll(ab & lt);            // survivor rank of ORIGINAL position tid
-        __syncthreads();
+        {
+            const unsigned long long m0 = s_alive[0], m1 = s_alive[1], m2 = s_alive[2], m3 = s_alive[3];
+            const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2);
+            total = c0 + c1 + c2 + __popcll(m3);
+            if (alive) {
+                const int w = src >> 6;
+                const unsigned long long mw = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
+                my_rank = (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0) + __popcll(mw & ((1ull << (src & 63)) - 1ull));
+            }
+        }
         if (alive) {
-            my_rank = s_perm[src];
             const int s2 = b * NT + my_rank;
             if (COMPACT) {
                 st4(io.nxt.o_pix, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.pix)));
