@@ -1268,6 +1268,8 @@ __device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, con
 // prevPdf outside MIS (lightPDF, pathtrace.cu:547-554) nor the hit distance beyond its sign, and (uv, geomID, triangleID) only with textures
 // or MIS — so the four 16-byte streams are  paths.o_pix = (direction, pixelIndex), paths.d_bnc = (color, remainingBounces),
 // hits.t_n = (normal, hit rank: the `hr` word), hits.p_mat = (point, materialId); col_pdf, uv_ids and the hr array stay untouched.
+// MIS adds a fifth stream, paths.col_pdf = (origin, prevPdf), and stores the primitive instead of the material in hits.p_mat.w (lightPDF needs
+// geomID; the material id is a field of the primitive's staged record; triangleID is -1 without triangles): 80 B per path instead of 100.
 // The timed configuration is partly bound by HBM traffic (+32 B per path costs 5.7 %, measured): −24 % bytes per path-bounce.
 template <int MODE, bool GEN, bool SPLIT, bool COMPACT>
 #ifndef PTK_FUSED_WAVES_BSDF
@@ -1335,6 +1337,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             if (COMPACT) {
                 st4(io.nxt.o_pix, i, make_float4(d.x, d.y, d.z, __int_as_float((sidx << 24) | (x + y * gen.cam.W))));
                 st4(io.nxt.d_bnc, i, make_float4(1.f, 1.f, 1.f, __int_as_float(gen.trace_depth)));
+                if (MODE == PTK_MODE_MIS) st4(io.nxt.col_pdf, i, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, -1.f));
             } else {
                 st4(io.nxt.o_pix, i, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, __int_as_float((sidx << 24) | (x + y * gen.cam.W))));
                 st4(io.nxt.d_bnc, i, make_float4(d.x, d.y, d.z, __int_as_float(gen.trace_depth)));
@@ -1392,6 +1395,12 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
                 p.o = mk3(0, 0, 0); p.pix = __float_as_int(a4.w);
                 p.d = mk3(a4.x, a4.y, a4.z); p.bounces = __float_as_int(b4.w);
                 p.col = mk3(b4.x, b4.y, b4.z); p.prevPdf = -1.f;
+                if (MODE == PTK_MODE_MIS) {
+                    const float4 c4 = ld4(io.cur.col_pdf, ps);
+                    p.o = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+                    h.geom = __float_as_int(h1.w);
+                    h.mat = gs.on ? __float_as_int(gs.xf[(size_t)h.geom * PTK_XF_FLOATS + 34]) : S.geoms[h.geom].materialid;
+                }
             } else {
                 const float4 h0 = ld4(io.hcur.t_n, ps), h1 = ld4(io.hcur.p_mat, ps);
                 const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(io.hcur.uv_ids, ps);
@@ -1426,6 +1435,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             if (COMPACT) {
                 st4(io.nxt.o_pix, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.pix)));
                 st4(io.nxt.d_bnc, s2, make_float4(p.col.x, p.col.y, p.col.z, __int_as_float(p.bounces)));
+                if (MODE == PTK_MODE_MIS) st4(io.nxt.col_pdf, s2, make_float4(p.o.x, p.o.y, p.o.z, p.prevPdf));
             } else {
                 st4(io.nxt.o_pix, s2, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
                 st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
@@ -1496,7 +1506,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
             if (active) {
                 const int word = flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1;      // rank < 256; the type is the next launch's sort key
                 st4(io.hnxt.t_n, slot, make_float4(h.n.x, h.n.y, h.n.z, __int_as_float(word)));
-                if (flag) st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(h.mat)));
+                if (flag) st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(MODE == PTK_MODE_MIS ? h.geom : h.mat)));
             }
         } else {
             io.hr_nxt[slot] = active ? (flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1) : -2;
@@ -1621,10 +1631,15 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
                     const float4 a4 = ld4(cur.o_pix, src), b4 = ld4(cur.d_bnc, src), h0 = ld4(A.hits0.t_n, src);
                     p.pix = __float_as_int(a4.w); p.d = mk3(a4.x, a4.y, a4.z); p.bounces = __float_as_int(b4.w);
                     p.col = mk3(b4.x, b4.y, b4.z); p.prevPdf = -1.f;
+                    if (MODE == PTK_MODE_MIS) { const float4 c4 = ld4(cur.col_pdf, src); p.o = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w; }
                     flag = __float_as_int(h0.w) >= 0;
                     if (flag) {
                         const float4 h1 = ld4(A.hits0.p_mat, src);
                         h.t = 1.0f; h.n = mk3(h0.x, h0.y, h0.z); h.p = mk3(h1.x, h1.y, h1.z); h.mat = __float_as_int(h1.w);
+                        if (MODE == PTK_MODE_MIS) {
+                            h.geom = h.mat;
+                            h.mat = gs.on ? __float_as_int(gs.xf[(size_t)h.geom * PTK_XF_FLOATS + 34]) : S.geoms[h.geom].materialid;
+                        }
                     }
                 } else {
                 const float4 o4 = ld4(cur.o_pix, src), d4 = ld4(cur.d_bnc, src), c4 = ld4(cur.col_pdf, src);
@@ -1964,12 +1979,12 @@ static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, co
                                 const TraceIO& io, float* img, unsigned plane_stride, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
     const int g = grid_for(capacity);
     if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
-    else if (compact && MODE != PTK_MODE_MIS) k_shade_trace<MODE, GEN, false, (MODE != PTK_MODE_MIS)><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    else if (compact) k_shade_trace<MODE, GEN, false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     return launch_rc();
 }
 // the fused pipeline's compact stream layout (k_shade_trace): no triangles, no textures, no MIS
-bool trace_compact(const SceneView& S, int mode) { return S.n_tris == 0 && S.n_tex == 0 && mode != PTK_MODE_MIS; }
+bool trace_compact(const SceneView& S, int mode) { (void)mode; return S.n_tris == 0 && S.n_tex == 0; }
 int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool)) {
@@ -2002,6 +2017,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     int rc;
     if (gen) {
         switch (mode) {                 // (the mode only matters for the hit-record layout the next launch expects: same kernel body)
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;   // (the MIS layouts carry the origin)
         default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
         }
     } else {
