@@ -101,7 +101,7 @@ int context_free() {
         dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
-        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.ws.list_src); dfree(l.iter_dev);
+        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
         if (l.graph) (void)hipGraphDestroy(l.graph);
         if (l.done) (void)hipEventDestroy(l.done);
@@ -173,7 +173,6 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.counts, (size_t)g.traceDepth + 2))) return rc;
     if ((rc = dalloc(&l.ws.queue, 1))) return rc;
     if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.ws.list_src, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
     if ((rc = dalloc(&l.ws.srcidx, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.ws.seg_pref, blocks + 16))) return rc;

@@ -51,7 +51,6 @@ struct Workspace {               // per-render-context scratch, device memory
     unsigned long long* stats = nullptr;       // optional node/triangle counters
     unsigned* queue = nullptr;   // length of the traversal work list (rays that entered the BVH root box)
     int* list = nullptr;         // the work list [capacity]
-    int* list_src = nullptr;     // physical slots of the listed rays (segmented streams) [capacity]
     int* iter_dev = nullptr;     // device-resident iteration number (hipGraph replay); null = use the launch argument
     int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
     unsigned plane_stride = 0;   // floats per radiance plane (3*P)

@@ -422,9 +422,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg,
 
 // stable compaction of the flagged ray indices into the traversal work list (same scheme as k_scatter, 4-byte payload)
 __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
-                                                     const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count, int whole_windows,
-                                                     const int* __restrict__ srcidx, int* __restrict__ list_src) {
-    // list_src (staged pipeline): the listed ray's physical slot, so that the walk kernels load the ray without a second dependent gather
+                                                     const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count, int whole_windows) {
     int n = d_n ? *d_n : n_arg;
     if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;      // fused pipeline: flags live at physical slots, every slot of a window is written
     const int b = blockIdx.x;
@@ -434,7 +432,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __rest
     int total;
     const int local = block_excl_prefix(flag, total);
     const int prior = prior_blocks(heavy_agg, b);
-    if (flag) { list[prior + local] = i; if (list_src) list_src[prior + local] = srcidx ? srcidx[i] : i; }
+    if (flag) list[prior + local] = i;
     if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *list_count = (unsigned)(prior + total);
 }
 
@@ -450,7 +448,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
     unsigned nv = 0, nt = 0;
     if (j < m) {
         const int ray = list[j];
-        const int src = srcidx ? srcidx[j] : ray;                      // physical slot of the listed ray (written by k_list; null: slots are dense / physical)
+        const int src = srcidx ? srcidx[ray] : ray;                    // physical slot of dense path `ray` (segmented streams)
         const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         const float t0 = hits.t_n[4 * (size_t)ray];                   // analytic closest t, -1 = none
         Walk w;
@@ -561,7 +559,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
     unsigned nv = 0, nt = 0;
     if (j < m) {
         const int ray = list[j];
-        const int src = srcidx ? srcidx[j] : ray;                        // (k_list's list_src)
+        const int src = srcidx ? srcidx[ray] : ray;
         const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         const float t0 = hits.t_n[4 * (size_t)ray];
         WideRay r;
@@ -1896,10 +1894,7 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
-                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED, int wide_lpr = 4,
-                           int* list_src = nullptr) {
-    // list_src (optional, [capacity]): k_list also records the listed rays' physical slots there (segmented streams), else the walk kernels
-    // look them up through G.src themselves
+                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED, int wide_lpr = 4) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
@@ -1913,21 +1908,15 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg, G);
     else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg, G);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    const int* walk_src = G.src;
-    if (G.src && list_src) { k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0, G.src, list_src); walk_src = list_src; }
-    else k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0, nullptr, nullptr);
+    k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
-    // (walk_src is indexed by LIST POSITION when it is k_list's list_src; the kernels below index their source table by list position too:
-    //  without list_src they get a table made on the fly — see the fallback in the kernels)
-    const bool by_pos = walk_src == list_src && list_src != nullptr;
-    if (!by_pos && G.src) return PTK_E_BADARG;            // the segmented pipeline always provides list_src
-    if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, walk_src);
-    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, walk_src);
-    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, walk_src);
-    else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, walk_src);
-    else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, walk_src);
+    if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg);
     mark(1, false);
@@ -1952,7 +1941,7 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
     if (seg && depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
     // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
-                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr, ws.list_src);
+                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr);
     if (rc) return rc;
     if (S.env_tex >= 0) {
         k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride, G.src);
@@ -2045,7 +2034,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     const int n_bound = gen ? n_pix * ws.spp : capacity;
     if (split) {
         mark(1, true);
-        k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1, nullptr, nullptr);
+        k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
         const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
         if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
