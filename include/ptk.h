@@ -224,7 +224,8 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *       survivors while their new rays are still in registers (the first launch of an iteration generates the camera rays
  *       instead of shading); path state and hit record are written together at the survivor's slot in its block's window, the
  *       compacted slot of a hit path (the reference's RNG key) is hit_pref[window] + its rank among the window's hits, and the last
- *       block of every launch builds the window tables.  Scenes with triangles continue each launch with the work-list BVH stage
+ *       block of every launch builds the window tables.  Triangle-free scenes without textures use compact streams (four 16-byte
+ *       records per path, five in MIS: only what shading really reads, with the rank and the material type in one word).  Scenes with triangles continue each launch with the work-list BVH stage
  *       (stable compaction of the rays that enter the root box, BVH walk over the list, finalize).  While the traversal counters
  *       are enabled the staged kernels of 8 run instead (they keep the counters);
  *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the
