@@ -275,9 +275,9 @@ def roofline_valu(scene_file, roof):
         return None
     rate = c["SQ_INSTS_VALU"] / (roof["avg_launch_us"] * 1e-6)
     return {"achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
-            "insts_valu_per_launch": c["SQ_INSTS_VALU"], "packed_share_static": c.get("packed_share_static"), "kernel": roof.get("kernel"),
-            "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the vector ALUs are "
-                    "~0.8 busy (valu_busy_estimate).  Packed instructions counted once here; their static share of the kernel's VALU instructions is packed_share_static"}
+            "insts_valu_per_launch": c["SQ_INSTS_VALU"], "kernel": roof.get("kernel"),
+            "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the pipeline's instructions "
+                    "fill the issue slots (valu_busy_estimate ~ 1.0).  Packed instructions counted once; what an instruction really costs: profiles/r3_issue_cost.txt"}
 
 
 def main():
