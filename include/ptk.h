@@ -187,7 +187,9 @@ int ptk_set_graph_replay(int on);
 int ptk_get_image(float* host_out);
 /* Device pointer of the radiance buffer (float[3*P]) for collectives; valid until ptk_pathtrace_free. */
 int ptk_get_image_device(float** out);
-/* Device-to-device copy of the radiance buffer into caller-owned device memory (e.g. a tensor handed to RCCL). */
+/* Device-to-device copy of the radiance buffer into caller-owned device memory (e.g. a tensor handed to RCCL).  Runs on the render
+ * context's own NON-BLOCKING stream and synchronises it before returning; work the caller has queued on dst on another stream (a fill,
+ * say) must have completed before the call — the Python binding waits for torch's current stream. */
 int ptk_copy_image_to_device(float* dst_device);
 /* Per-bounce live-path counts of the LAST ptk_pathtrace call (counts[trace_depth+1], host); synchronises.
  * *traced_depth = number of bounces with live paths (guiData->TracedDepth, pathtrace.cu:793-796). */

@@ -23,7 +23,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # anything else is the default bit-exact library.  One flavour per process (the library holds the render context).
 FLAVOUR = os.environ.get("PTK_FLAVOUR", "") or "exact"       # "fma", or the name of a diagnostic build libptk_<name>.so (tools/diag)
 if FLAVOUR != "exact" and not os.path.exists(os.path.join(CSRC, f"libptk_{FLAVOUR}.so")):
-    FLAVOUR = "exact"
+    raise ImportError(f"PTK_FLAVOUR={FLAVOUR}: {os.path.join(CSRC, f'libptk_{FLAVOUR}.so')} does not exist (make -C csrc / tools/diag/build_variant.sh)")
 LIB_PATH = os.path.join(CSRC, "libptk.so" if FLAVOUR == "exact" else f"libptk_{FLAVOUR}.so")
 REPO_ROOT = os.path.dirname(_HERE)
 SCENES = os.path.join(REPO_ROOT, "scenes")
@@ -328,6 +328,10 @@ class Renderer:
         return out
 
     def image_to(self, tensor):
+        """radiance sum -> a caller-owned device tensor.  The render streams are non-blocking, so nothing orders work the caller queued
+        on ITS stream (e.g. the zero-fill of a fresh torch.zeros) against the copy: wait for the caller's stream first."""
+        import torch
+        torch.cuda.current_stream(tensor.device).synchronize()
         _chk(lib.ptk_copy_image_to_device(_ptr(tensor)), "ptk_copy_image_to_device")
 
     def live_counts(self):

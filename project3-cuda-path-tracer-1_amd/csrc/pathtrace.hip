@@ -225,6 +225,9 @@ int context_init(Scene* scene) {
     g.lanes.assign(g.n_lanes, Lane());
     for (int i = 0; i < g.n_lanes; ++i) if ((rc = lane_init(g.lanes[i], i))) return rc;
     g.last_lane = 0;
+    // the two hipMemset above run on the NULL stream and the lanes' streams are non-blocking: nothing else orders the clears before the
+    // first iteration's radiance adds (seen once with two processes sharing a GPU: a few pixels of the first iterations lost)
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
     g.live = true;
     return 0;
 }
@@ -568,7 +571,8 @@ int ptk_debug_slot_shift(int k) { g_debug_slot_shift = k; invalidate_graphs(); r
 int ptk_debug_clear_image(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();
-    return rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
+    const int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
+    return rc ? rc : rc_of(hipDeviceSynchronize());      // null-stream clear vs the lanes' non-blocking streams
 }
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it

@@ -884,9 +884,10 @@ PTK_DI int closest_hit(const SceneView& S, const GeomStage& gs, f3 ro, f3 rd, Hi
     return closest_hit_finish<STATS>(S, a, ro, rd, h, nodeVisits, triTests);
 }
 
-// LightSampler::occulusionTest, lightSample.h:59-139
-PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3 des) {
-    float minT = length(des - ori);
+// LightSampler::occulusionTest, lightSample.h:59-139 — in two parts (analytic primitives, lightSample.h:61-88; the BVH walk, :90-125) so
+// that the fused kernel's deferred shadow phase can run the first part block-cooperatively (analytic_anyhit_lds, ptk_kernels.hip) and the
+// second per lane.  minT = length(des - ori), computed by the caller exactly as the reference does at the top of the function.
+PTK_DI bool occluded_analytic(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, float minT) {
     if (!gs.on) {
         float t = 0.f;
         for (int i = 0; i < S.n_geoms; ++i) {
@@ -920,6 +921,9 @@ PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3
             }
         }
     }
+    return false;
+}
+PTK_DI bool occluded_bvh(const SceneView& S, f3 ori, f3 dir, float minT) {
     if (S.n_tris == 0) return false;
     const DevNode* nodes = S.nodes + (size_t)mtbvh_dir(dir) * S.bvh_size;
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -938,6 +942,10 @@ PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3
         idx = nd.b;
     }
     return false;
+}
+PTK_DI bool occluded(const SceneView& S, const GeomStage& gs, f3 ori, f3 dir, f3 des) {
+    const float minT = length(des - ori);
+    return occluded_analytic(S, gs, ori, dir, minT) || occluded_bvh(S, ori, dir, minT);
 }
 
 // material parameters at a hit: the four devTexSampler::linearSample(uv) calls of material.h, resolved once
@@ -1130,6 +1138,11 @@ PTK_DI float mat_pdf(const MatEval& m, f3 n, f3 wo, f3 wi) {     // Material::pd
 
 // ---- light sampling (lightSample.h) -----------------------------------------------------------------
 struct LightRec { f3 pos, emit; float pdf; bool is_zero; };
+// A shadow ray whose occlusion test is deferred (fused kernel, MIS / DIRECT): light_sample writes the ray and reports the sample
+// as unoccluded; the caller stores the contribution it WOULD add in `contrib` and adds it after the block's shadow phase if the ray is free.
+// The ray itself is parked in the caller's LDS slot at once — (origin, minT), (direction, pixel) — so that it is not held in registers while the
+// BSDF of the sample is evaluated.
+struct ShadowReq { bool on; float4* slot; int pix; f3 contrib; };
 
 // LightSampler::lightPDF, lightSample.h:141-169
 // Opt-in "fixed" cube lights (ptk_set_light_fix; NOT reference behaviour): world-space areas of the three face
@@ -1168,7 +1181,7 @@ PTK_DI float light_pdf(const SceneView& S, f3 viewPos, f3 lightPos, f3 normal, i
 }
 
 // LightSampler::lightSample, lightSample.h:171-248.  rng is a COPY (by-value parameter in the reference).
-PTK_DI void light_sample(const SceneView& S, const GeomStage& gs, const DevMaterial* mats, f3 viewPos, Rng rng, LightRec& rec) {
+PTK_DI void light_sample(const SceneView& S, const GeomStage& gs, const DevMaterial* mats, f3 viewPos, Rng rng, LightRec& rec, ShadowReq* defer = nullptr) {
     rec.pos = mk3(0, 0, 0); rec.emit = mk3(0, 0, 0); rec.pdf = 0.f; rec.is_zero = true;
     int Li = S.n_lights;
     if (Li == 0) return;
@@ -1243,7 +1256,12 @@ PTK_DI void light_sample(const SceneView& S, const GeomStage& gs, const DevMater
         rec.pdf = 0.f; return;
     }
     f3 rayDir = normalize(lightPos - viewPos);
-    if (occluded(S, gs, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = mk3(0, 0, 0); rec.pdf = -1.f; return; }
+    if (defer) {
+        const f3 ori = viewPos + 1e-5f * rayDir;
+        defer->slot[0] = make_float4(ori.x, ori.y, ori.z, length(lightPos - ori));
+        defer->slot[1] = make_float4(rayDir.x, rayDir.y, rayDir.z, __int_as_float(defer->pix));
+        defer->on = true;
+    } else if (occluded(S, gs, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = mk3(0, 0, 0); rec.pdf = -1.f; return; }
     const DevMaterial& lm = mats[geom.materialid];
     rec.emit = mk3(lm.albedo[0], lm.albedo[1], lm.albedo[2]);
     rec.pdf = pdf; rec.pos = lightPos; rec.is_zero = false;

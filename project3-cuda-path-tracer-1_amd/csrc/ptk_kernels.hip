@@ -261,6 +261,64 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
         a.P = mk3(r0.x, r0.y, r1.x); a.NS = mk3(r1.y, r2.x, r2.y);
     }
 }
+// Any-hit over the analytic primitives for the block's SHADOW rays (the first loop of LightSampler::occulusionTest, lightSample.h:61-88),
+// block-cooperatively like analytic_closest_lds: candidate test per ray, one LDS pair list (cube pairs from the front, sphere pairs behind
+// them), thread j tests pairs j, j + NT, ... and ORs the reference's occlusion condition into the ray's bit of a 256-bit LDS mask.  The
+// result is a boolean OR over the primitives — order-independent, and the primitives the candidate test culls provably miss (returns 0,
+// tests/test_candidate_margin.py) — so it equals the per-lane loop of occluded_analytic.  All NT threads must call it; ends with a barrier.
+//   L.ray[2 r] = (origin, minT), L.ray[2 r + 1] = (direction, -) of shadow ray r, written by thread r before the caller's last barrier.
+template <int NT, int LP>
+__device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, unsigned long long* s_occ, bool active, f3 ro, f3 rd) {
+    constexpr int NW = NT / 64;
+    constexpr int RB = NT == 512 ? 9 : 8;
+    const float4* s_ray = L.ray; unsigned short* s_list = L.list; int* s_cnt = L.cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int base = 0; base < S.n_geoms; base += 32) {
+        const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
+        const Cand call = analytic_candidates(S, base, n, ro, rd);
+        for (int half = 0; half * LP < n; ++half) {
+            Cand c = call;
+            const unsigned hm = ((1u << LP) - 1u) << (LP * half);
+            c.cube &= hm; c.sphere &= hm;
+            if (!active) { c.cube = 0u; c.sphere = 0u; }
+            const int v = __popc(c.cube) | (__popc(c.sphere) << 16);
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) s_cnt[wid] = incl;
+            __syncthreads();
+            int woff_c = 0, woff_s = 0, Tc = 0, Ts = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int cw = s_cnt[w];
+                if (w < wid) { woff_c += cw & 0xffff; woff_s += cw >> 16; }
+                Tc += cw & 0xffff; Ts += cw >> 16;
+            }
+            int oc = woff_c + ((incl - v) & 0xffff), os = Tc + woff_s + ((incl - v) >> 16);
+            for (unsigned m = c.cube; m; m &= m - 1u) s_list[oc++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
+            for (unsigned m = c.sphere; m; m &= m - 1u) s_list[os++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
+            __syncthreads();
+            const int T = Tc + Ts;
+            for (int r0 = 0; r0 < T; r0 += NT) {
+                const int pi = r0 + tid;
+                if (pi < T) {
+                    const unsigned e = s_list[pi];
+                    const int r = (int)(e & ((1u << RB) - 1u));
+                    const int k = (int)(e >> RB);
+                    const float4 o4 = s_ray[2 * r], d4 = s_ray[2 * r + 1];
+                    const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
+                    const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
+                    const float minT = o4.w;
+                    f3 tp, tn;
+                    const float t = pi < Tc ? box_test(g, po, pd, tp, tn) : sphere_test(g, po, pd, tp, tn);
+                    if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) atomicOr(&s_occ[r >> 6], 1ull << (r & 63));
+                }
+            }
+            __syncthreads();                              // the list is rewritten by the next pass; the last one publishes s_occ
+        }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const GeomStage& gs, bool active, f3 ro, f3 rd, Analytic& a) {
     __shared__ float4 s_ray[2 * NT];
@@ -780,8 +838,12 @@ __device__ __forceinline__ MatTable stage_materials(const SceneView& S, DevMater
     return mt;
 }
 
+// rq != nullptr (fused kernel, MIS / DIRECT): the next-event shadow ray is NOT tested here — the sample is evaluated as if it were free, its
+// contribution goes to rq->contrib instead of the film, and the caller adds it after the block's shadow phase if the ray is unoccluded.  Same
+// values, same single read-modify-write of the pixel within the launch: bit-identical to the inline form.
 template <int MODE>
-__device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& gs, const MatTable& mt, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img) {
+__device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& gs, const MatTable& mt, int iter, int slot, int depth, const Hit& h, PathRegs& p, const Film& img,
+                                          ShadowReq* rq = nullptr) {
     if (h.t <= 0.f) { p.col = p.col * 0.f; p.bounces = 0; return 0; }
     const DevMaterial mrec = fetch_material(S, mt, h.mat);
     const MatEval m = eval_material(S, mrec, h.uv);
@@ -794,12 +856,13 @@ __device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& g
             return 0;
         }
         LightRec li;
-        light_sample(S, gs, S.mats, h.p, rng, li);
-        if (li.pdf <= 0) { p.col = p.col * 0.f; return 0; }
+        light_sample(S, gs, S.mats, h.p, rng, li, rq);
+        if (li.pdf <= 0) { p.col = p.col * 0.f; if (rq) rq->on = false; return 0; }
         const f3 wi = normalize(li.pos - h.p);
         const f3 f = mat_bsdf(m, h.n, p.d, wi);
         p.col = p.col * (f * li.emit * gmax(dot(wi, h.n), 0.f) / li.pdf);
-        add_radiance(img, p.pix, nan_to_zero(p.col));
+        if (rq) rq->contrib = nan_to_zero(p.col);
+        else add_radiance(img, p.pix, nan_to_zero(p.col));
         return 0;
     }
     Scatter s;
@@ -824,14 +887,15 @@ __device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& g
     const bool isDelta = (m.type == PTK_MAT_DIELECTRIC);
     if (MODE == PTK_MODE_MIS && !isDelta) {
         LightRec li;
-        light_sample(S, gs, S.mats, h.p, rng, li);                        // rng by value: the path's stream does not advance
+        light_sample(S, gs, S.mats, h.p, rng, li, rq);                    // rng by value: the path's stream does not advance
         if (!li.is_zero) {
             const f3 wi = normalize(li.pos - h.p);
             const float bp = mat_pdf(m, h.n, p.d, wi);
             const float lp = li.pdf;
             const f3 f = mat_bsdf(m, h.n, p.d, wi);
             const float w = power_heuristic(lp, bp);
-            add_radiance(img, p.pix, nan_to_zero(w * p.col * li.emit * f * gmax(dot(wi, h.n), 0.f) / lp));
+            const f3 c = nan_to_zero(w * p.col * li.emit * f * gmax(dot(wi, h.n), 0.f) / lp);
+            if (rq) rq->contrib = c; else add_radiance(img, p.pix, c);
         }
     }
     const f3 offsetDir = dot(s.dir, h.n) > 0 ? h.n : -h.n;
@@ -1275,7 +1339,13 @@ template <int MODE, bool GEN, bool SPLIT, bool COMPACT>
 #ifndef PTK_FUSED_WAVES_BSDF
 #define PTK_FUSED_WAVES_BSDF 7
 #endif
-__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE == PTK_MODE_DIRECTLI ? 6 : PTK_FUSED_WAVES_BSDF))) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+#ifndef PTK_FUSED_WAVES_MIS
+#define PTK_FUSED_WAVES_MIS 6
+#endif
+#ifndef PTK_FUSED_WAVES_DIRECT
+#define PTK_FUSED_WAVES_DIRECT 6
+#endif
+__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF))) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
                                                              const int* __restrict__ d_n, TraceIO io, float* __restrict__ img_base, unsigned plane_stride,
                                                              int spp, int slot_bias, SegTail2 tail) {
     constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6;
@@ -1295,6 +1365,10 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
     __shared__ int s_red[NW];
     __shared__ int s_tcnt[NW];
     __shared__ unsigned long long s_alive[NT / 64];
+    // MIS / DIRECT: next-event shadow rays are deferred to a block-cooperative phase between shading and tracing (DEFER_NEE below)
+    constexpr bool DEFER_NEE = !GEN && MODE != PTK_MODE_BSDF;
+    __shared__ unsigned long long s_occ[NT / 64];
+    __shared__ int s_anyreq;
     DevMaterial* s_mats = reinterpret_cast<DevMaterial*>(s_over);
     int* s_perm = reinterpret_cast<int*>(s_over + MATS * sizeof(DevMaterial));
     int* s_slot = s_perm + NT;
@@ -1313,12 +1387,15 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         }
         return;
     }
-    if (tid < NT / 64) s_alive[tid] = 0ull;                        // (published by the barrier in stage_geoms / stage_materials)
+    if (tid < NT / 64) { s_alive[tid] = 0ull; if (DEFER_NEE) { s_occ[tid] = 0ull; s_anyreq = 0; } }      // (published by the barrier in stage_geoms / stage_materials)
     const GeomStage gs = stage_geoms(S);                           // the trace phase always needs the primitives; MIS / DIRECT shading too
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int alive = 0, my_rank = -1;           // this thread's shaded path survives, at rank my_rank of the window
     int total = 0;                         // survivors of the block
+    // shadow ray of thread t -> slots 2t, 2t + 1 of the (still idle) upper half of the trace phase's LDS: s_res / s_best are first written
+    // inside analytic_closest_lds
+    ShadowReq rq; rq.on = false; rq.slot = s_stage + 2 * NT + 2 * tid; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
     if (GEN) {
         // ---- generateRayFromCamera: path i -> pixel through the tile partition, sample s of the batch (see k_generate)
         total = min(NT, n - b * NT);
@@ -1414,7 +1491,9 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
                 p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
                 p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
             }
-            alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
+            rq.pix = p.pix;
+            alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img, DEFER_NEE ? &rq : nullptr);
+            if (DEFER_NEE && rq.on) s_anyreq = 1;
         }
         // survivor rank in the ORIGINAL (dense) order — the next bounce's compacted order, hence its RNG keys: every survivor sets the bit of
         // its original position in a 256-bit LDS mask, one barrier, rank = set bits below it (five barriers with a flag array + ballot before)
@@ -1446,6 +1525,24 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? 4 : (MODE =
         }
     }
     __syncthreads();                           // shading tables are dead, s_ray is complete: the pair list may overwrite s_over
+    if (DEFER_NEE && s_anyreq) {               // block-uniform
+        // ---- shadow phase (LightSampler::occulusionTest, lightSample.h:59-139) for the block's next-event samples.  Inside shade_path the
+        // test is a per-lane candidate loop that runs max-over-lanes trips per wave and holds the shading state in registers meanwhile
+        // (MIS: 109 VGPRs = four waves per SIMD; without it 87 = five).  Here: analytic primitives block-cooperatively, the BVH per lane.
+        const TraceLds Lsh = {s_stage + 2 * NT, nullptr, nullptr, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
+        bool occ = false;
+        f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0); float s_minT = 0.f; int s_pix = 0;
+        if (rq.on) { const float4 o4 = rq.slot[0], d4 = rq.slot[1]; so = mk3(o4.x, o4.y, o4.z); s_minT = o4.w; sd = mk3(d4.x, d4.y, d4.z); s_pix = __float_as_int(d4.w); }
+        if (gs.on) {
+            analytic_anyhit_lds<NT, LP>(S, gs, Lsh, s_occ, rq.on, so, sd);
+            occ = (s_occ[tid >> 6] >> (tid & 63)) & 1ull;
+        } else {
+            if (rq.on) occ = occluded_analytic(S, gs, so, sd, s_minT);
+            __syncthreads();                   // (analytic_anyhit_lds ends with a barrier: the rays are dead before the trace phase writes s_best)
+        }
+        if (SPLIT && rq.on && !occ) occ = occluded_bvh(S, so, sd, s_minT);
+        if (rq.on && !occ) add_radiance(img, s_pix, rq.contrib);
+    }
     // ---- trace phase: thread t < total traces survivor t of the window (computeIntersections, pathtrace.cu:169-346)
     int hits = 0;
     if (total > 0) {                           // block-uniform
