@@ -581,14 +581,20 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
 struct WideRay { f3 o, d, inv; float t_min; int tri; float u, v; int dir; };
 
 // conservative test of one child record against the ray (see above); A/Bn/Bf are per visit, per axis
-struct WideFrame { float Ax, Ay, Az, Bnx, Bny, Bnz, Bfx, Bfy, Bfz; bool px, py, pz; };
+// selN / selF: v_perm_b32 selectors, fixed per ray, that gather the three NEAR (resp. FAR) plane bytes of a child record — the low plane
+// of an axis the ray travels up, the high plane otherwise — into bytes 0..2 of one word: two instructions per child instead of six selects
+struct WideFrame { float Ax, Ay, Az, Bnx, Bny, Bnz, Bfx, Bfy, Bfz; unsigned selN, selF; };
+__device__ __forceinline__ void wide_frame_selectors(bool px, bool py, bool pz, WideFrame& f) {
+    // record bytes: c.x = lox, loy, loz, hix; c.y = hiy, hiz, ...  (perm(c.y, c.x, sel): selector values 0-3 take bytes of c.x, 4-7 of c.y, 0x0c = 0)
+    f.selN = 0x0c000000u | (px ? 0u : 3u) | ((py ? 1u : 4u) << 8) | ((pz ? 2u : 5u) << 16);
+    f.selF = 0x0c000000u | (px ? 3u : 0u) | ((py ? 4u : 1u) << 8) | ((pz ? 5u : 2u) << 16);
+}
 __device__ __forceinline__ bool wide_child_test(const uint4 c, const WideFrame& f, float t_min) {
-    const float lox = (float)(c.x & 0xffu), loy = (float)((c.x >> 8) & 0xffu), loz = (float)((c.x >> 16) & 0xffu);
-    const float hix = (float)(c.x >> 24), hiy = (float)(c.y & 0xffu), hiz = (float)((c.y >> 8) & 0xffu);
-    const float tn = fmaxf(fmaxf(__builtin_fmaf(f.px ? lox : hix, f.Ax, f.Bnx), __builtin_fmaf(f.py ? loy : hiy, f.Ay, f.Bny)),
-                           __builtin_fmaf(f.pz ? loz : hiz, f.Az, f.Bnz));
-    const float tf = fminf(fminf(__builtin_fmaf(f.px ? hix : lox, f.Ax, f.Bfx), __builtin_fmaf(f.py ? hiy : loy, f.Ay, f.Bfy)),
-                           __builtin_fmaf(f.pz ? hiz : loz, f.Az, f.Bfz));
+    const unsigned nb = __builtin_amdgcn_perm(c.y, c.x, f.selN), fb = __builtin_amdgcn_perm(c.y, c.x, f.selF);
+    const float nx = (float)(nb & 0xffu), ny = (float)((nb >> 8) & 0xffu), nz = (float)((nb >> 16) & 0xffu);
+    const float fx = (float)(fb & 0xffu), fy = (float)((fb >> 8) & 0xffu), fz = (float)((fb >> 16) & 0xffu);
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(nx, f.Ax, f.Bnx), __builtin_fmaf(ny, f.Ay, f.Bny)), __builtin_fmaf(nz, f.Az, f.Bnz));
+    const float tf = fminf(fminf(__builtin_fmaf(fx, f.Ax, f.Bfx), __builtin_fmaf(fy, f.Ay, f.Bfy)), __builtin_fmaf(fz, f.Az, f.Bfz));
     return tn <= fminf(tf, t_min) && tf >= 0.f;
 }
 __device__ __forceinline__ unsigned wide_before(const uint4 c, int dir) {      // before[dir] of a child record
@@ -618,13 +624,15 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
                                                               const int* __restrict__ srcidx) {
     constexpr int RAYS = PTK_BLOCK / LPR, NCH = 8 / LPR;          // rays per block; children per lane
-    __shared__ uint4 s_top[PTK_WIDE_TOP * 9];
+    __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
     __shared__ unsigned s_stack[RAYS * PTK_WIDE_STRIDE];
     const int m = (int)*list_count;
     if (blockIdx.x * RAYS >= m) return;
     const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
-    for (int k = threadIdx.x; k < n_top * 9; k += PTK_BLOCK) s_top[k] = S.wnodes[k];
-    __syncthreads();
+    if (PTK_WIDE_TOP > 0) {
+        for (int k = threadIdx.x; k < n_top * 9; k += PTK_BLOCK) s_top[k] = S.wnodes[k];
+        __syncthreads();
+    }
     const int q = threadIdx.x & (LPR - 1);                       // lane within the ray's group
     const int qsh = (threadIdx.x & 63) & ~(LPR - 1);             // first lane of the group within the wave
     const int j = blockIdx.x * RAYS + threadIdx.x / LPR;
@@ -645,13 +653,13 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
         if (!threaded) {
             unsigned* stk = s_stack + (threadIdx.x / LPR) * PTK_WIDE_STRIDE;
             WideFrame f;
-            f.px = r.inv.x > 0.f; f.py = r.inv.y > 0.f; f.pz = r.inv.z > 0.f;
+            wide_frame_selectors(r.inv.x > 0.f, r.inv.y > 0.f, r.inv.z > 0.f, f);
             int sp = 0;
             unsigned cur = 0u;                                   // root
             for (;;) {
                 if (!(cur & PTK_WIDE_LEAF)) {
                     uint4 q0, ch[NCH];                           // lane q owns children q, q + LPR, ...
-                    if ((int)cur < n_top) {
+                    if (PTK_WIDE_TOP > 0 && (int)cur < n_top) {
                         const uint4* np = s_top + cur * 9; q0 = np[0];
 #pragma unroll
                         for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
@@ -667,7 +675,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
                     f.Ax = sx * r.inv.x; f.Ay = sy * r.inv.y; f.Az = sz * r.inv.z;                     // exact (power-of-two scale)
                     const float Bx = (__uint_as_float(q0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(q0.y) - r.o.y) * r.inv.y, Bz = (__uint_as_float(q0.z) - r.o.z) * r.inv.z;
                     const float K = 9.5367431640625e-07f;                                              // 2^-20
-                    const float mx = K * (fabsf(Bx) + 255.f * fabsf(f.Ax)) + 1e-36f, my = K * (fabsf(By) + 255.f * fabsf(f.Ay)) + 1e-36f, mz = K * (fabsf(Bz) + 255.f * fabsf(f.Az)) + 1e-36f;
+                    // m = 2^-20 (|B| + 255 |A|) + 1e-36, twice the rounding bound: two fused steps per axis (any rounding of m itself is
+                    // far inside that factor of two; the walk only prunes, so both library flavours find the same hits)
+                    const float K255 = 255.f * K;
+                    const float mx = __builtin_fmaf(K255, fabsf(f.Ax), __builtin_fmaf(K, fabsf(Bx), 1e-36f)), my = __builtin_fmaf(K255, fabsf(f.Ay), __builtin_fmaf(K, fabsf(By), 1e-36f)),
+                                mz = __builtin_fmaf(K255, fabsf(f.Az), __builtin_fmaf(K, fabsf(Bz), 1e-36f));
                     f.Bnx = Bx - mx; f.Bfx = Bx + mx; f.Bny = By - my; f.Bfy = By + my; f.Bnz = Bz - mz; f.Bfz = Bz + mz;
                     const int nc = (int)(q0.w >> 24);
                     bool hit[NCH];
@@ -675,9 +687,15 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
                         hit[k] = (q + LPR * k < nc) & wide_child_test(ch[k], f, r.t_min);      // no short circuit: straight-line code
-                        const unsigned long long bal = __ballot(hit[k]);
-                        H |= ((unsigned)(bal >> qsh) & ((1u << LPR) - 1u)) << (LPR * k);
+                        if (LPR == 2 || LPR == 4) H |= hit[k] ? (1u << (q + LPR * k)) : 0u;    // own bits; the group's lanes are ORed below
+                        else {
+                            const unsigned long long bal = __ballot(hit[k]);
+                            H |= ((unsigned)(bal >> qsh) & ((1u << LPR) - 1u)) << (LPR * k);
+                        }
                     }
+                    // the lanes of a pair / quad always run together (one ray, one control flow): exchange the masks with quad permutes
+                    if (LPR == 2 || LPR == 4) H |= (unsigned)__builtin_amdgcn_mov_dpp((int)H, 0xB1, 0xf, 0xf, true);      // lanes 1 0 3 2
+                    if (LPR == 4) H |= (unsigned)__builtin_amdgcn_mov_dpp((int)H, 0x4E, 0xf, 0xf, true);                  // lanes 2 3 0 1
                     const int nh = __popc(H);
                     if (sp + nh > PTK_WIDE_STACK) { threaded = true; break; }
                     // all hit children at once, in reverse visiting order: the child visited first ends on top
@@ -688,6 +706,10 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const 
                 } else {
                     const uint4* lp = S.wleaves + (size_t)(cur & ~PTK_WIDE_LEAF) * 4;
                     const uint4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
+#ifdef PTK_DIAG_DOUBLE_LEAF      // timing experiments only: the leaf visit runs twice on laundered inputs (same results)
+                    { WideRay r2 = r; asm volatile("" : "+v"(r2.o.x), "+v"(r2.d.x), "+v"(r2.inv.x)); (void)wide_leaf_visit(l0, l1, l2, l3, r2);
+                      asm volatile("" :: "v"(r2.t_min), "v"(r2.tri), "v"(r2.u), "v"(r2.v)); }
+#endif
                     (void)wide_leaf_visit(l0, l1, l2, l3, r);
                     if (STATS) nt += (q == 0);
                 }
