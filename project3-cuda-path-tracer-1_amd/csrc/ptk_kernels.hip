@@ -319,15 +319,18 @@ __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const Ge
     }
 }
 
+#ifndef PTK_INTERSECT_LP
+#define PTK_INTERSECT_LP 16      // primitives per pass of k_intersect's pair list (8 KB of LDS; the fused kernel uses 8)
+#endif
 template <int NT>
 __device__ __forceinline__ void analytic_closest_block(const SceneView& S, const GeomStage& gs, bool active, f3 ro, f3 rd, Analytic& a) {
     __shared__ float4 s_ray[2 * NT];
     __shared__ float2 s_res[3 * NT];
     __shared__ unsigned long long s_best[NT];
-    __shared__ unsigned short s_list[NT * 16];
+    __shared__ unsigned short s_list[NT * PTK_INTERSECT_LP];
     __shared__ int s_cnt[NT / 64];
     const TraceLds L = {s_ray, s_res, s_best, s_list, s_cnt};
-    analytic_closest_lds<NT, false>(S, gs, L, active, ro, rd, a);
+    analytic_closest_lds<NT, false, PTK_INTERSECT_LP>(S, gs, L, active, ro, rd, a);
 }
 
 // Segmented path streams (default render pipeline).  The shading kernel writes the survivors of its block contiguously at
@@ -414,8 +417,11 @@ static inline size_t stage_bytes(const SceneView& S) { return S.lds_geoms > 0 ? 
 // ------------------------------------------------------------------------------------------------------------------
 #define PTK_VALID_TRI 2          // flag value between k_traverse and k_finalize: "closest hit is a triangle, record pending"
 
+#ifndef PTK_INTERSECT_WAVES
+#define PTK_INTERSECT_WAVES 1
+#endif
 template <bool STATS, bool SPLIT>
-__global__ void __launch_bounds__(PTK_BLOCK) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
+__global__ void __launch_bounds__(PTK_BLOCK, PTK_INTERSECT_WAVES) k_intersect(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
                                                           PtkHits hits, int* __restrict__ valid, int* __restrict__ agg,
                                                           unsigned long long* ray_total, unsigned long long* stats,
                                                           int* __restrict__ heavy_flag, int* __restrict__ heavy_agg, Gather G) {

@@ -68,3 +68,13 @@ def test_product_does_not_touch_the_oracle():
                     code = line.split("#")[0] if f == "Makefile" else line.split("//")[0]
                     if "#include" in code or f == "Makefile":
                         assert "oracle" not in code, (path, line)
+
+
+def test_missing_flavour_library_fails_loudly():
+    """PTK_FLAVOUR names a library that was not built: the binding must refuse to import instead of silently loading the default
+    library (an A/B measurement of round 3 compared the default with itself that way)."""
+    import subprocess, sys
+    env = dict(os.environ, PTK_FLAVOUR="no_such_flavour")
+    code = "import importlib, sys; sys.path.insert(0, %r); importlib.import_module('project3-cuda-path-tracer-1_amd')" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "PTK_FLAVOUR=no_such_flavour" in r.stderr, r.stderr[-300:]
