@@ -98,7 +98,7 @@ int context_free() {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
         dfree(l.hitsB.t_n); dfree(l.hitsB.p_mat); dfree(l.hitsB.uv_ids); dfree(l.hrA); dfree(l.hrB);
-        dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy);
+        dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy); dfree(l.ws.hcounts); dfree(l.ws.seg_first_h);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
         dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
@@ -166,6 +166,8 @@ int lane_init(Lane& l, int idx) {
     const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;
     if ((rc = dalloc(&l.ws.agg_h, blocks))) return rc;
     if ((rc = dalloc(&l.ws.hit_pref, blocks + 16))) return rc;
+    if ((rc = dalloc(&l.ws.seg_first_h, blocks + 16))) return rc;
+    if ((rc = dalloc(&l.ws.hcounts, (size_t)g.traceDepth + 2))) return rc;
     if ((rc = dalloc(&l.ws.agg_a, blocks))) return rc;
     if ((rc = dalloc(&l.ws.agg_b, blocks))) return rc;
     if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
@@ -183,6 +185,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.seg_done = fold_segments(g.pipeline, g.n_lanes) ? l.seg_done_mem : nullptr;
     if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(l.ws.hcounts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
     l.ws.inline_bvh = (g.pipeline == 1 || g.pipeline == 2);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);

@@ -1264,14 +1264,15 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
 struct TraceIO {
     // the bounce being shaded (unused with GEN): paths, their hit records and hit ranks at PHYSICAL slots, the window tables
     PtkPaths cur; PtkHits hcur; const int* hr_cur;
-    const int* pref; const int* first; const int* hit_pref;
+    const int* pref; const int* first; const int* hit_pref; const int* first_h;      // first_h: COMPACT (hit-dense shading)
     // the bounce being traced: survivors (or fresh camera rays), their hit records and ranks
     PtkPaths nxt; PtkHits hnxt; int* hr_nxt;
     int* agg_s; int* agg_h;              // per-window survivor / hit counts of this launch
     int* valid_nxt;                      // SPLIT: 0 / 1 / -2 per slot for k_traverse / k_finalize
     int* heavy_flag; int* heavy_agg;     // SPLIT: rays that enter the BVH root box
 };
-struct SegTail2 { int* done; int* pref; int* first; int* hit_pref; int* count_out; int* iter_advance; int iter_stride; unsigned long long* ray_total; };
+struct SegTail2 { int* done; int* pref; int* first; int* hit_pref; int* count_out; int* iter_advance; int iter_stride; unsigned long long* ray_total;
+                  int* first_h; int* hcount_out; };      // COMPACT (hit-dense shading): window of hit index 256 B, total hits of the launch
 struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix; };
 
 // segments_block for the fused launches: the window prefix of the survivor counts (pref / first / next live count) AND the prefix of the hit
@@ -1279,7 +1280,8 @@ struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix
 // twice the barriers).  Four consecutive windows per thread; agg_h == nullptr: no hit prefix (SPLIT: k_finalize2 builds it).
 template <int NT>
 __device__ __forceinline__ void segments_block2(int n_prev, const int* __restrict__ agg_s, const int* __restrict__ agg_h, int* __restrict__ pref, int* __restrict__ first,
-                                                int* __restrict__ hit_pref, int* __restrict__ count_out, int* iter_advance, int iter_stride) {
+                                                int* __restrict__ hit_pref, int* __restrict__ count_out, int* iter_advance, int iter_stride,
+                                                int* __restrict__ first_h = nullptr, int* __restrict__ hcount_out = nullptr) {
     constexpr int NW = NT / 64;
     __shared__ int s_ws[NW], s_wh[NW];
     __shared__ int s_carry_s, s_carry_h;
@@ -1313,6 +1315,10 @@ __device__ __forceinline__ void segments_block2(int n_prev, const int* __restric
                 if (agg_h) hit_pref[idx + k] = eh;
                 const int B = (es + PTK_BLOCK - 1) / PTK_BLOCK;
                 if (cs[k] > 0 && B * PTK_BLOCK < es + cs[k]) first[B] = idx + k;
+                if (first_h) {                                   // the same table over the HIT order (the order the next launch shades in)
+                    const int Bh = (eh + PTK_BLOCK - 1) / PTK_BLOCK;
+                    if (ch[k] > 0 && Bh * PTK_BLOCK < eh + ch[k]) first_h[Bh] = idx + k;
+                }
             }
             es += cs[k]; eh += ch[k];
         }
@@ -1324,6 +1330,7 @@ __device__ __forceinline__ void segments_block2(int n_prev, const int* __restric
     if (tid < 8) { pref[nw + tid] = total; if (agg_h) hit_pref[nw + tid] = total_h; }
     if (tid == 0) {
         if (count_out) *count_out = total;
+        if (hcount_out) *hcount_out = total_h;
         if (iter_advance) *iter_advance += iter_stride;
     }
 }
@@ -1347,7 +1354,8 @@ __device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, 
     __syncthreads();
     if (!s_last) return;
     for (int k = threadIdx.x; k <= ng; k += NT) __hip_atomic_store(T.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    segments_block2<NT>(n, agg_s, (T.hit_pref && agg_h) ? agg_h : nullptr, T.pref, T.first, T.hit_pref, T.count_out, T.iter_advance, T.iter_stride);
+    segments_block2<NT>(n, agg_s, (T.hit_pref && agg_h) ? agg_h : nullptr, T.pref, T.first, T.hit_pref, T.count_out, T.iter_advance, T.iter_stride,
+                        (T.hit_pref && agg_h) ? T.first_h : nullptr, (T.hit_pref && agg_h) ? T.hcount_out : nullptr);
     if (threadIdx.x == 0 && T.ray_total) atomicAdd(T.ray_total, (unsigned long long)*T.count_out);     // rays of the bounce just traced
 }
 
@@ -1424,6 +1432,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_W
         // no live path at all: nobody runs the tail, block 0 does the (empty) bookkeeping of the bounce
         if (n <= 0 && b == 0) {
             if (tail.hit_pref && tid < 8) tail.hit_pref[tid] = 0;
+            if (tail.hcount_out && tid == 0) *tail.hcount_out = 0;
             segments_block<NT, false>(0, io.agg_s, tail.pref, tail.first, tail.count_out, tail.iter_advance, tail.iter_stride);
         }
         return;
@@ -1468,20 +1477,38 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_W
         // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
         const int iter = (step - 1) * spp + 1;
         const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
-        int hit_base = 0;
         // windows of the stream being read = ceil(paths the previous launch shaded / 256); the camera launch's stream (depth 0) is dense
         const int nw_prev = depth > 0 ? (d_n[-1] + NT - 1) / NT : (gen.n_pix * spp + NT - 1) / NT;
-        const int src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, nw_prev, hit_base);      // 0 for i >= n
-        // one word per path at the head — rank among the window's hits | material type << 8 (the sort key), -1 for a miss: in the normal's
-        // spare word (COMPACT) or in the hr array.  (Reading the material id from the hit record here, a second strided stream ahead of
-        // the sort, cost 12 % of the headline.)
-        const int hr_word = (i < n) ? (COMPACT ? __float_as_int(io.hcur.t_n[4 * (size_t)src_mine + 3]) : io.hr_cur[src_mine]) : -1;
-        const int flag = hr_word >= 0;
-        // (SPLIT: k_finalize2 writes the word — a triangle hit's material is only known there)
-        const int hr = hr_word & 0xff;
+        int src_mine = 0, flag = 0, key = NKEY - 1, slot_mine = 0;
+        if (COMPACT) {
+            // HIT-DENSE shading: n and i count the paths of the previous launch that HIT something, in stream order — which is the reference's
+            // compacted slot, the RNG key, itself.  A miss is never shaded (h.t <= 0: colour 0, no radiance, dead), so it is never even loaded: an
+            // open scene (mis_test.txt: 200 435 hits among 1 048 576 camera rays, 4 953 among the 196 540 rays of bounce 1) runs 783 + 20 full
+            // blocks instead of 4 096 + 768 mostly idle ones.  Hit index -> window by the hit prefix (five scalar loads, first_h[b] = the
+            // window of hit 256 b); hit r of window w sits at the slot the tracing block recorded in inv[256 w + r] (with the material type,
+            // the sort key).  Survivors keep their order, so every later key is unchanged.
+            const int w0 = io.first_h[b];
+            const int h0 = io.hit_pref[w0], h1 = io.hit_pref[w0 + 1], h2 = io.hit_pref[w0 + 2], h3 = io.hit_pref[w0 + 3], h4 = io.hit_pref[w0 + 4];
+            if (i < n) {
+                int k = (i >= h1) + (i >= h2) + (i >= h3) + (i >= h4);
+                int base = k == 0 ? h0 : (k == 1 ? h1 : (k == 2 ? h2 : (k == 3 ? h3 : h4)));
+                if (k == 4) k = sparse_window(io.hit_pref, w0 + 4, nw_prev, i, base) - w0;
+                const int word = io.hr_cur[(w0 + k) * NT + (i - base)];
+                src_mine = (w0 + k) * NT + (word & 0xff);
+                flag = 1; key = word >> 8; slot_mine = i + slot_bias;
+            }
+        } else {
+            int hit_base = 0;
+            src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, nw_prev, hit_base);      // 0 for i >= n
+            // one word per path at the head — rank among the window's hits | material type << 8 (the sort key), -1 for a miss, in the hr array.
+            // (Reading the material id from the hit record here, a second strided stream ahead of the sort, cost 12 % of the headline.)
+            const int hr_word = (i < n) ? io.hr_cur[src_mine] : -1;
+            flag = hr_word >= 0;
+            // (SPLIT: k_finalize2 writes the word — a triangle hit's material is only known there)
+            if (flag) key = hr_word >> 8;
+            slot_mine = hit_base + (hr_word & 0xff) + slot_bias;
+        }
         s_src[tid] = src_mine;
-        int key = NKEY - 1;
-        if (flag) key = hr_word >> 8;
         unsigned long long bal[NKEY];
 #pragma unroll
         for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
@@ -1498,7 +1525,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_W
             else if (key > k) rank += tot;
         }
         s_perm[rank] = tid;
-        s_slot[tid] = hit_base + hr + slot_bias;
+        s_slot[tid] = slot_mine;
         __syncthreads();
         int src = -1;
         PathRegs p;
@@ -1644,9 +1671,13 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_W
         } else if (COMPACT) {
             // hit record with the rank in the normal's spare word: only the slots of survivors are written (nobody reads the others)
             if (active) {
-                const int word = flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1;      // rank < 256; the type is the next launch's sort key
+                const int rank_h = before + __popcll(hb & lt), type = flag ? S.mats[h.mat].type : 0;
+                const int word = flag ? (rank_h | (type << 8)) : -1;      // rank < 256; k_tail reads the sign (hit / miss) when it takes over after this launch
                 st4(io.hnxt.t_n, slot, make_float4(h.n.x, h.n.y, h.n.z, __int_as_float(word)));
-                if (flag) st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(MODE == PTK_MODE_MIS ? h.geom : h.mat)));
+                if (flag) {
+                    st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(MODE == PTK_MODE_MIS ? h.geom : h.mat)));
+                    io.hr_nxt[b * NT + rank_h] = tid | (type << 8);      // inv: hit r of this window -> its slot, and the next launch's sort key
+                }
             }
         } else {
             io.hr_nxt[slot] = active ? (flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1) : -2;
@@ -1728,6 +1759,7 @@ __device__ __forceinline__ int block_excl_prefix_n(int flag, int& total) {
 struct TailArgs {
     int iter_arg; const int* iter_ptr; int depth0, trace_depth;
     int* counts;                             // counts[d] = live paths entering bounce d (read at depth0, written above)
+    const int* nshaded;                      // paths the last full-width launch shaded (its windows = ceil / 256): counts[depth0 - 1], or hcounts[depth0 - 1] after a hit-dense launch
     PtkPaths cur, nxt;                       // cur: the stream entering bounce depth0 (windowed if G.pref != null)
     Gather G;
     float* img; unsigned plane_stride; int spp, slot_bias;
@@ -1765,7 +1797,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
             h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
             p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
             if (i < n) {
-                const int src = gather_source(G, i / PTK_BLOCK, i, n, G.pref ? (A.counts[A.depth0 - 1] + PTK_BLOCK - 1) / PTK_BLOCK : 0);
+                const int src = gather_source(G, i / PTK_BLOCK, i, n, G.pref ? (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK : 0);
                 const bool traced = A.have_hits && depth == A.depth0;      // by the last full-width launch (ENV radiance of its misses added there)
                 if (traced && A.compact) {                                  // k_shade_trace's compact streams: (d, pix) (col, bounces) (n, rank) (p, mat)
                     const float4 a4 = ld4(cur.o_pix, src), b4 = ld4(cur.d_bnc, src), h0 = ld4(A.hits0.t_n, src);
@@ -2130,7 +2162,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
                        bool last, void (*mark)(int, bool)) {
     const int g = grid_for(capacity);
     if (g == 0) return 0;
-    if (!ws.seg_pref || !ws.seg_first || !ws.hit_pref || !ws.agg_h || !ws.agg_b || !ws.seg_done || !ws.tr_valid || !ws.tr_heavy) return PTK_E_BADARG;
+    if (!ws.seg_pref || !ws.seg_first || !ws.hit_pref || !ws.agg_h || !ws.agg_b || !ws.seg_done || !ws.tr_valid || !ws.tr_heavy || !ws.hcounts || !ws.seg_first_h) return PTK_E_BADARG;
     SceneView S = S_in;
     S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
     const bool split = S.n_tris > 0 && ws.queue && ws.list;
@@ -2145,13 +2177,15 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix;
     TraceIO io;
     io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr;
-    io.pref = ws.seg_pref; io.first = ws.seg_first; io.hit_pref = ws.hit_pref;
+    io.pref = ws.seg_pref; io.first = ws.seg_first; io.hit_pref = ws.hit_pref; io.first_h = ws.seg_first_h;
     io.nxt = nxt.paths; io.hnxt = nxt.hits; io.hr_nxt = nxt.hr;
     io.agg_s = ws.agg_b; io.agg_h = ws.agg_h;
     io.valid_nxt = ws.tr_valid; io.heavy_flag = ws.tr_heavy; io.heavy_agg = ws.agg_a;
-    // the launch that shades bounce dt - 1 reads counts[dt - 1]; its last block writes counts[dt] = the rays it traced
-    const int* d_n = gen ? nullptr : ws.counts + (dt - 1);
-    const SegTail2 tail = {ws.seg_done, ws.seg_pref, ws.seg_first, split ? nullptr : ws.hit_pref, ws.counts + dt, last ? ws.iter_dev : nullptr, ws.iter_stride, ws.ray_total};
+    // the launch that shades bounce dt - 1 reads counts[dt - 1]; its last block writes counts[dt] = the rays it traced.  COMPACT (hit-dense
+    // shading): it shades the hcounts[dt - 1] paths of bounce dt - 1 that hit something, and writes hcounts[dt] = the hits it found
+    const int* d_n = gen ? nullptr : (compact ? ws.hcounts : ws.counts) + (dt - 1);
+    const SegTail2 tail = {ws.seg_done, ws.seg_pref, ws.seg_first, split ? nullptr : ws.hit_pref, ws.counts + dt, last ? ws.iter_dev : nullptr, ws.iter_stride, ws.ray_total,
+                           compact ? ws.seg_first_h : nullptr, compact ? ws.hcounts + dt : nullptr};
     const int depth = dt - 1;           // RNG key depth of the bounce being shaded
     mark(gen ? 0 : 2, true);
     int rc;
@@ -2202,6 +2236,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     if (hits0) S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;      // as the launch that wrote them
     A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth0 = depth0; A.trace_depth = trace_depth;
     A.counts = ws.counts; A.cur = cur; A.nxt = nxt;
+    A.nshaded = (depth0 > 0 ? ((A.compact && ws.hcounts) ? ws.hcounts : ws.counts) + (depth0 - 1) : ws.counts);
     const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
     A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
