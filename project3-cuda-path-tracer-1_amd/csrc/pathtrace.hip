@@ -46,6 +46,7 @@ struct Lane {
     hipEvent_t counts_ev = nullptr;
     bool counts_pending = false;
     int graph_full = -1;                // full-width bounces the captured graph contains
+    int graph_late = -1;                // the camera launch's store placement the captured graph contains (g.gen_late)
     int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
     bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
     int fresh_hint = 0;                 // iterations enqueued on this lane since the hint was reset (read-backs every iteration at first)
@@ -66,6 +67,7 @@ struct RenderContext {
     bool use_graph = false;
     int last_lane = 0;
     int full_bounces = 0;               // bounces enqueued at full width; the rest of an iteration runs in k_tail (sparse_tail())
+    int gen_late = 0;                   // open scene (fewer than ~half of the camera rays hit, learnt like full_bounces): the camera launch stores the hits' path state only
     int hint_mode = -1;                 // sample mode the full_bounces hint was learnt under
     int n_shards = 1, shard = 0;        // iteration sharding (ptk_set_iteration_sharding): call `step` renders iteration (step-1)*n_shards + shard + 1
     bool live = false;
@@ -144,7 +146,7 @@ int lane_init(Lane& l, int idx) {
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
-    if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * ((size_t)g.traceDepth + 2), hipHostMallocDefault)) != hipSuccess) return (int)e;
+    if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * ((size_t)g.traceDepth + 2 + 1), hipHostMallocDefault)) != hipSuccess) return (int)e;      // + hcounts[0]
     l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
     l.ws.plane_stride = g.spp > 1 ? 3u * (unsigned)g.P : 0u;      // 0: no sample-plane bits in pixelIndex (pixel_ptr, ptk_kernels.hip)
     l.ws.spp = g.spp;
@@ -205,6 +207,7 @@ int context_init(Scene* scene) {
     g.P = cam.resolution.x * cam.resolution.y;
     g.traceDepth = scene->state.traceDepth;
     g.full_bounces = g.traceDepth;                  // until live counts of earlier iterations say otherwise (note_counts)
+    g.gen_late = 0;
     g.hint_mode = -1;
     if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
     g.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
@@ -272,6 +275,7 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
     ws.iter_stride = g.n_lanes * g.n_shards;
     ws.slot_bias += g_debug_slot_shift;
+    ws.gen_late = g.gen_late;
     const int full = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
     if (use_trace_pipeline()) {
         // launch 0 generates the camera rays and traces bounce 0; launch dt shades bounce dt - 1 and traces bounce dt (k_shade_trace)
@@ -322,6 +326,13 @@ void note_counts(Lane& L) {
     for (int d = 1; d < g.traceDepth; ++d) if (L.h_counts[d] <= kTailPaths) { d_new = d; break; }
     // hysteresis: widen at once, narrow only when the count is clearly below the threshold (no graph re-capture ping-pong)
     if (d_new > g.full_bounces || (d_new < g.full_bounces && L.h_counts[d_new] <= kTailPaths / 2)) g.full_bounces = d_new;
+    // camera rays that hit something / camera rays (fused pipeline, compact streams): below ~half, the camera launch stores the path state of
+    // the hits only, after its trace phase (k_shade_trace, GenArgs::late_stores); hysteresis as above.  Results never depend on it.
+    const long long n0 = L.h_counts[0], h0 = L.h_counts[g.traceDepth + 2];
+    if (n0 > 0 && use_trace_pipeline()) {
+        if (!g.gen_late && 100 * h0 < 45 * n0) g.gen_late = 1;
+        else if (g.gen_late && 100 * h0 > 55 * n0) g.gen_late = 0;
+    }
 }
 int request_counts(Lane& L) {
     if (!sparse_tail() || L.counts_pending) return 0;
@@ -329,6 +340,7 @@ int request_counts(Lane& L) {
     if (++L.fresh_hint > 8 && L.fresh_hint % 16 != 0) return 0;
     hipError_t e = hipMemcpyAsync(L.h_counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
     if (e != hipSuccess) return (int)e;
+    if ((e = hipMemcpyAsync(L.h_counts + g.traceDepth + 2, L.ws.hcounts, sizeof(int), hipMemcpyDeviceToHost, L.stream)) != hipSuccess) return (int)e;
     if ((e = hipEventRecord(L.counts_ev, L.stream)) != hipSuccess) return (int)e;
     L.counts_pending = true;
     return 0;
@@ -358,7 +370,7 @@ int build_graph(Lane& L, int iter, int mode) {
 
 int replay_iteration(Lane& L, int iter, int mode) {
     hipError_t e;
-    if (!L.graph_exec || L.graph_mode != mode || L.graph_full != g.full_bounces) {
+    if (!L.graph_exec || L.graph_mode != mode || L.graph_full != g.full_bounces || L.graph_late != g.gen_late) {
         const int rc = build_graph(L, iter, mode);
         if (rc == -1000) {
             // capture / instantiate refused by the runtime: same kernels, launched one by one (identical results)
@@ -369,7 +381,7 @@ int replay_iteration(Lane& L, int iter, int mode) {
             return enqueue_iteration(L, iter, mode, false);
         }
         if (rc) return rc;
-        L.graph_mode = mode; L.graph_full = g.full_bounces;
+        L.graph_mode = mode; L.graph_full = g.full_bounces; L.graph_late = g.gen_late;
         L.expected_iter = -1;
     }
     if (L.expected_iter != iter) {           // first replay, or the caller jumped in the iteration sequence
@@ -402,7 +414,7 @@ int render_iteration(unsigned char* pbo, int step) {
     if (mode != g.hint_mode) {
         // the full-width hint was learnt from another sample mode's live counts (DIRECT dies after one bounce, BSDF
         // does not): start again from "every bounce at full width" and ignore read-backs that are still in flight
-        g.full_bounces = g.traceDepth;
+        g.full_bounces = g.traceDepth; g.gen_late = 0;
         for (Lane& l : g.lanes) { l.counts_pending = false; l.fresh_hint = 0; }
         g.hint_mode = mode;
     }

@@ -65,6 +65,7 @@ struct Workspace {               // per-render-context scratch, device memory
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     // fused pipeline (k_shade_trace): per-window hit counts and their prefix, the SPLIT stage's per-slot flags
     int* agg_h = nullptr; int* hit_pref = nullptr; int* tr_valid = nullptr; int* tr_heavy = nullptr;
+    int gen_late = 0;            // host hint (pathtrace.hip: note_counts): the camera launch stores the hits' path state only, after its trace phase
     int* hcounts = nullptr;      // fused pipeline, compact streams: hcounts[d] = paths of bounce d that hit something [depth + 2]
     int* seg_first_h = nullptr;  // ... and the window of hit index 256 B [blocks + 16]
     int wide_lpr = 4;            // lanes per ray of the wide walk (4 or 2; ptk_kernels.hip k_traverse_wide)

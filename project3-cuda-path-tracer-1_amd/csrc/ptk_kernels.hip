@@ -1273,7 +1273,7 @@ struct TraceIO {
 };
 struct SegTail2 { int* done; int* pref; int* first; int* hit_pref; int* count_out; int* iter_advance; int iter_stride; unsigned long long* ray_total;
                   int* first_h; int* hcount_out; };      // COMPACT (hit-dense shading): window of hit index 256 B, total hits of the launch
-struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix; };
+struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix, late_stores; };
 
 // segments_block for the fused launches: the window prefix of the survivor counts (pref / first / next live count) AND the prefix of the hit
 // counts (hit_pref) in ONE pass — the last block of a launch runs alone, its time is on every lane's critical path (two separate scans took
@@ -1447,10 +1447,10 @@ __global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_W
     // inside analytic_closest_lds
     ShadowReq rq; rq.on = false; rq.slot = s_stage + 2 * NT + 2 * tid; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
     int gen_pixw = 0;                      // GEN + COMPACT: the camera ray's pixel word, stored with the path state after the trace phase
-    // ... when the scene is open.  The camera rays' hit count of this lane's PREVIOUS iteration is still in hcounts[0] (the last block of this
-    // launch overwrites it after every other block has finished): fewer than half hit -> store the path state after the trace phase, for the
-    // hits only; otherwise before it, where the stores overlap the tracing (measured on cornell.txt: 22.8 vs 22.6 Grays/s).  Same values either way.
-    const bool gen_late = GEN && COMPACT && tail.hcount_out != nullptr && 2 * (*tail.hcount_out) < n;
+    // ... when the scene is open (gen.late_stores: the host saw fewer than ~half of the camera rays of earlier iterations hit something);
+    // otherwise before it, where the stores overlap the tracing (cornell.txt: 22.8 vs 22.6 Grays/s).  Same values either way.  (Deciding here
+    // from hcounts[0] of the lane's previous iteration puts a dependent load ahead of the stores: -3 % on cornell.txt DIRECT.)
+    const bool gen_late = GEN && COMPACT && gen.late_stores != 0;
     if (GEN) {
         // ---- generateRayFromCamera: path i -> pixel through the tile partition, sample s of the batch (see k_generate)
         total = min(NT, n - b * NT);
@@ -2189,7 +2189,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     G.cam.up = mk3(cam.up.x, cam.up.y, cam.up.z);
     G.cam.right = mk3(cam.right.x, cam.right.y, cam.right.z);
     G.cam.plx = cam.pixelLength.x; G.cam.ply = cam.pixelLength.y;
-    G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix;
+    G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix; G.late_stores = ws.gen_late;
     TraceIO io;
     io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr;
     io.pref = ws.seg_pref; io.first = ws.seg_first; io.hit_pref = ws.hit_pref; io.first_h = ws.seg_first_h;
