@@ -207,6 +207,10 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 int ptk_set_iteration_sharding(int n_shards, int shard);
 /* Bounces currently enqueued at full width (the remaining ones run in the single-workgroup tail kernel); diagnostic. */
 int ptk_get_full_width_bounces(int* out);
+/* 1 when the render loop has learnt (hit counts of earlier iterations, fused pipeline with compact streams) that fewer than about half of the
+ * camera rays hit anything: the camera launch then stores the path state of the hits only, after its trace phase (generateRayFromCamera,
+ * pathtrace.cu:120-167, writes every path; a miss is never read again here).  Diagnostic; results never depend on it. */
+int ptk_get_open_scene_hint(int* out);
 /* Test-only: offset k added to the compacted slot in the shading RNG key (pathtrace.cu:363,458,532), and a reset of the radiance
  * buffer.  tests/test_gallery.py renders the reference's gallery/Direct20.png with the slot offsets its GPU build ran with. */
 int ptk_debug_slot_shift(int k);

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
     "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_light_fix",
-    "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_debug_slot_shift", "ptk_debug_clear_image", "ptk_debug_exact_math",
+    "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_get_open_scene_hint", "ptk_debug_slot_shift", "ptk_debug_clear_image", "ptk_debug_exact_math",
 ]
 
 
@@ -143,6 +143,7 @@ def _load() -> C.CDLL:
     lib.ptk_set_light_fix.argtypes = [ci]
     lib.ptk_set_iteration_sharding.argtypes = [ci, ci]
     lib.ptk_get_full_width_bounces.argtypes = [C.POINTER(ci)]
+    lib.ptk_get_open_scene_hint.argtypes = [C.POINTER(ci)]
     lib.ptk_debug_slot_shift.argtypes = [ci]
     lib.ptk_debug_exact_math.argtypes = [C.c_ulonglong, C.c_uint, vp, vp]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
@@ -344,6 +345,11 @@ class Renderer:
     def full_width_bounces(self) -> int:
         d = C.c_int(0)
         _chk(lib.ptk_get_full_width_bounces(C.byref(d)), "ptk_get_full_width_bounces")
+        return d.value
+
+    def open_scene_hint(self) -> int:
+        d = C.c_int(0)
+        _chk(lib.ptk_get_open_scene_hint(C.byref(d)), "ptk_get_open_scene_hint")
         return d.value
 
     def ray_total(self) -> int:

@@ -572,6 +572,12 @@ int ptk_set_iteration_sharding(int n_shards, int shard) {
 }
 /* Bounces the render loop currently enqueues at full width (the rest of an iteration runs in the single-workgroup k_tail);
  * trace depth until live counts of earlier iterations have been seen.  Diagnostic. */
+int ptk_get_open_scene_hint(int* out) {
+    if (!g.live) return PTK_E_NOSCENE;
+    if (!out) return PTK_E_BADARG;
+    *out = g.gen_late;
+    return 0;
+}
 int ptk_get_full_width_bounces(int* out) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!out) return PTK_E_BADARG;

@@ -267,6 +267,11 @@ def _sparse_tail(ptk, orc, name, res, depth, mode, lanes, pipeline):
         ref = ref + p
     img = r.image()
     assert r.ray_total() == rays
+    # the camera launch's store placement (hits only, after the trace phase, in open scenes) is learnt the same way: both placements ran above
+    if pipeline == 0 and name.startswith("mis_test"):
+        assert r.open_scene_hint() == 1
+    if name == "cornell.txt":
+        assert r.open_scene_hint() == 0
     r.close()
     assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
