@@ -1394,7 +1394,10 @@ template <int MODE, bool GEN, bool SPLIT, bool COMPACT>
 #ifndef PTK_FUSED_WAVES_DIRECT
 #define PTK_FUSED_WAVES_DIRECT 6
 #endif
-__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF))) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
+#ifndef PTK_FUSED_WAVES_GEN
+#define PTK_FUSED_WAVES_GEN 0     // > 0: occupancy the camera launches are compiled for; 0: that of their mode (measured: MIS layout 22.2 at six vs 21.1 Grays/s at seven on mis_test)
+#endif
+__global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ? PTK_FUSED_WAVES_GEN : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF)))) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
                                                              const int* __restrict__ d_n, TraceIO io, float* __restrict__ img_base, unsigned plane_stride,
                                                              int spp, int slot_bias, SegTail2 tail) {
     constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6;
