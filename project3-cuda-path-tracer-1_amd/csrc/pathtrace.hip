@@ -140,6 +140,16 @@ static int pick_walk(int pipeline, int n_lanes) {
     return pipeline == 5 ? PTK_WALK_THREADED : PTK_WALK_WIDE;
 }
 
+// The BVH walk inside the intersect kernel (pipelines 1 / 2) instead of the work-list stage (k_list + k_traverse_wide + k_finalize): three
+// launches fewer per bounce, which is what a mesh of a dozen triangles costs in the first place.  Pipeline 0 picks it for tiny meshes —
+// measured on the BASELINE configs[2] scene obj_test.txt (cube.obj, 12 triangles): 12.95 vs 11.07 Grays/s; sphere.obj (320 triangles) is
+// already far on the other side (15.3 vs 37.0).  Identical results (test_alternative_pipelines).
+constexpr int kInlineBvhMaxTris = 32;
+bool inline_bvh_choice(int which) {
+    if (which == 1 || which == 2) return true;
+    return which == 0 && g.scene && g.scene->tempDevScene.tri_num > 0 && g.scene->tempDevScene.tri_num <= kInlineBvhMaxTris;
+}
+
 int lane_init(Lane& l, int idx) {
     int rc;
     hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
@@ -189,7 +199,7 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.hcounts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
-    l.ws.inline_bvh = (g.pipeline == 1 || g.pipeline == 2);
+    l.ws.inline_bvh = inline_bvh_choice(g.pipeline);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4;          // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
     l.ws.segmented = (g.pipeline != 4);
@@ -598,7 +608,7 @@ int ptk_debug_clear_image(void) {
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = (which == 1 || which == 2); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     return 0;
