@@ -141,9 +141,10 @@ static int pick_walk(int pipeline, int n_lanes) {
 }
 
 // The BVH walk inside the intersect kernel (pipelines 1 / 2) instead of the work-list stage (k_list + k_traverse_wide + k_finalize): three
-// launches fewer per bounce, which is what a mesh of a dozen triangles costs in the first place.  Pipeline 0 picks it for tiny meshes —
-// measured on the BASELINE configs[2] scene obj_test.txt (cube.obj, 12 triangles): 12.95 vs 11.07 Grays/s; sphere.obj (320 triangles) is
-// already far on the other side (15.3 vs 37.0).  Identical results (test_alternative_pipelines).
+// launches fewer per bounce, which is what a mesh of a dozen triangles costs in the first place.  Pipeline 0 picks it for tiny meshes, and
+// then runs the fused launches with the walk in their trace phase (one launch per bounce) — measured on the BASELINE configs[2] scene
+// obj_test.txt (cube.obj, 12 triangles): staged + work list 11.07, staged + inline walk 12.95, fused + inline walk 14.14 Grays/s;
+// sphere.obj (320 triangles) is already far on the other side (inline 15.3 vs work list 37.0).  Identical results.
 constexpr int kInlineBvhMaxTris = 32;
 bool inline_bvh_choice(int which) {
     if (which == 1 || which == 2) return true;
@@ -274,7 +275,7 @@ bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 4 && g.pipeline != 
 // the staged kernels are 1-3 % ahead (bunny scene 5.70 vs 5.62 Grays/s); the traversal counters are only kept by the staged kernels
 bool use_trace_pipeline() {
     if (!trace_pipeline(g.pipeline) || (g.lanes.size() && g.lanes[0].ws.stats)) return false;
-    return g.pipeline == 10 || g.scene->tempDevScene.tri_num == 0;
+    return g.pipeline == 10 || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline);      // (tiny mesh: walked inside the fused kernel)
 }
 void no_mark(int, bool) {}
 

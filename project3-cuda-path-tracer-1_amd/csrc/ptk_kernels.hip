@@ -1623,7 +1623,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             if (rq.on) occ = occluded_analytic(S, gs, so, sd, s_minT);
             __syncthreads();                   // (analytic_anyhit_lds ends with a barrier: the rays are dead before the trace phase writes s_best)
         }
-        if (SPLIT && rq.on && !occ) occ = occluded_bvh(S, so, sd, s_minT);
+        if ((SPLIT || !COMPACT) && rq.on && !occ) occ = occluded_bvh(S, so, sd, s_minT);      // (returns at once without triangles)
         if (rq.on && !occ) add_radiance(img, s_pix, rq.contrib);
     }
     // ---- trace phase: thread t < total traces survivor t of the window (computeIntersections, pathtrace.cu:169-346)
@@ -1644,7 +1644,16 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
         if (active) {
             flag = a.geom >= 0;
-            if (flag) { if (gs.on) analytic_record_staged(gs.xf, a, h); else analytic_record(S, a, h); }
+            int wtri = -1;
+            if (!SPLIT && !COMPACT && S.n_tris > 0) {
+                // tiny mesh (the launcher sends meshes of up to kInlineBvhMaxTris triangles here): the reference's own walk, in this lane,
+                // seeded with the analytic winner (pathtrace.cu:236-279) — no work list, no BVH stage, one launch per bounce
+                Walk w;
+                walk_begin(S, ro, rd, a.t_min, w);
+                while (w.idx != -1) (void)walk_step(S, w);
+                if (w.tri >= 0) { triangle_record(S, w.tri, w.u, w.v, w.t_min, h); wtri = w.tri; flag = 1; }
+            }
+            if (flag && wtri < 0) { if (gs.on) analytic_record_staged(gs.xf, a, h); else analytic_record(S, a, h); }
 #ifdef PTK_DIAG_DOUBLE_RECORD    // timing experiments only
             if (flag && gs.on) { Analytic a2 = a; asm volatile("" : "+v"(a2.NS.x), "+v"(a2.NS.y), "+v"(a2.NS.z)); Hit h2; analytic_record_staged(gs.xf, a2, h2);
                                  asm volatile("" :: "v"(h2.n.x), "v"(h2.n.y), "v"(h2.n.z)); }
@@ -2183,7 +2192,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     if (!ws.seg_pref || !ws.seg_first || !ws.hit_pref || !ws.agg_h || !ws.agg_b || !ws.seg_done || !ws.tr_valid || !ws.tr_heavy || !ws.hcounts || !ws.seg_first_h) return PTK_E_BADARG;
     SceneView S = S_in;
     S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
-    const bool split = S.n_tris > 0 && ws.queue && ws.list;
+    const bool split = S.n_tris > 0 && !ws.inline_bvh && ws.queue && ws.list;       // inline_bvh (tiny mesh): the walk runs inside k_shade_trace's trace phase
     const bool compact = !split && trace_compact(S, mode);
     GenArgs G;
     G.cam.W = cam.resolution.x; G.cam.H = cam.resolution.y;

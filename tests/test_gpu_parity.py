@@ -589,6 +589,7 @@ FULL = [  # BASELINE.json configs at full size (oracle: a few seconds per iterat
     ("textureEnv_test.txt", None, -1, "MIS", 2),      # the reference's textured / ENV-mapped scene at its own RES 800x800 DEPTH 12
     ("sphere.txt", None, -1, "MIS", 1),               # at the file's own 800x800 depth 8
     ("disney_test.txt", None, -1, "BSDF", 1),
+    ("obj_test.txt", None, -1, "MIS", 2),             # configs[2] as shipped (12 triangles, no light): the fused kernel with the reference walk in its trace phase
 ]
 
 
