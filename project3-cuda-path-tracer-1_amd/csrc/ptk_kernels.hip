@@ -1263,10 +1263,10 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
 // ------------------------------------------------------------------------------------------------------------------
 struct TraceIO {
     // the bounce being shaded (unused with GEN): paths, their hit records and hit ranks at PHYSICAL slots, the window tables
-    PtkPaths cur; PtkHits hcur; const int* hr_cur;
+    PtkPaths cur; PtkHits hcur; const int* hr_cur; const int* inv_cur;      // inv: hit r of window w -> slot | type << 8 (hit-dense shading, every layout but SPLIT)
     const int* pref; const int* first; const int* hit_pref; const int* first_h;      // first_h: COMPACT (hit-dense shading)
     // the bounce being traced: survivors (or fresh camera rays), their hit records and ranks
-    PtkPaths nxt; PtkHits hnxt; int* hr_nxt;
+    PtkPaths nxt; PtkHits hnxt; int* hr_nxt; int* inv_nxt;
     int* agg_s; int* agg_h;              // per-window survivor / hit counts of this launch
     int* valid_nxt;                      // SPLIT: 0 / 1 / -2 per slot for k_traverse / k_finalize
     int* heavy_flag; int* heavy_agg;     // SPLIT: rays that enter the BVH root box
@@ -1493,7 +1493,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         // windows of the stream being read = ceil(paths the previous launch shaded / 256); the camera launch's stream (depth 0) is dense
         const int nw_prev = depth > 0 ? (d_n[-1] + NT - 1) / NT : (gen.n_pix * spp + NT - 1) / NT;
         int src_mine = 0, flag = 0, key = NKEY - 1, slot_mine = 0;
-        if (COMPACT) {
+        if (!SPLIT) {
             // HIT-DENSE shading: n and i count the paths of the previous launch that HIT something, in stream order — which is the reference's
             // compacted slot, the RNG key, itself.  A miss is never shaded (h.t <= 0: colour 0, no radiance, dead), so it is never even loaded: an
             // open scene (mis_test.txt: 200 435 hits among 1 048 576 camera rays, 4 953 among the 196 540 rays of bounce 1) runs 783 + 20 full
@@ -1506,7 +1506,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 int k = (i >= h1) + (i >= h2) + (i >= h3) + (i >= h4);
                 int base = k == 0 ? h0 : (k == 1 ? h1 : (k == 2 ? h2 : (k == 3 ? h3 : h4)));
                 if (k == 4) k = sparse_window(io.hit_pref, w0 + 4, nw_prev, i, base) - w0;
-                const int word = io.hr_cur[(w0 + k) * NT + (i - base)];
+                const int word = io.inv_cur[(w0 + k) * NT + (i - base)];
                 src_mine = (w0 + k) * NT + (word & 0xff);
                 flag = 1; key = word >> 8; slot_mine = i + slot_bias;
             }
@@ -1698,7 +1698,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 st4(io.hnxt.t_n, slot, make_float4(h.n.x, h.n.y, h.n.z, __int_as_float(word)));
                 if (flag) {
                     st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(MODE == PTK_MODE_MIS ? h.geom : h.mat)));
-                    io.hr_nxt[b * NT + rank_h] = tid | (type << 8);      // inv: hit r of this window -> its slot, and the next launch's sort key
+                    io.inv_nxt[b * NT + rank_h] = tid | (type << 8);     // inv: hit r of this window -> its slot, and the next launch's sort key
                     if (GEN && gen_late) {                               // (thread tid generated and traced camera ray `slot`)
                         st4(io.nxt.o_pix, slot, make_float4(rd.x, rd.y, rd.z, __int_as_float(gen_pixw)));
                         st4(io.nxt.d_bnc, slot, make_float4(1.f, 1.f, 1.f, __int_as_float(gen.trace_depth)));
@@ -1707,7 +1707,10 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 }
             }
         } else {
-            io.hr_nxt[slot] = active ? (flag ? ((before + __popcll(hb & lt)) | (S.mats[h.mat].type << 8)) : -1) : -2;
+            // (textures / ENV map / a tiny mesh walked in this kernel: the full-width streams.  hr: the slot's own status for k_env_miss2 and k_tail)
+            const int rank_h = before + __popcll(hb & lt), type = flag ? S.mats[h.mat].type : 0;
+            io.hr_nxt[slot] = active ? (flag ? (rank_h | (type << 8)) : -1) : -2;
+            if (flag) io.inv_nxt[b * NT + rank_h] = tid | (type << 8);
         }
     } else if (SPLIT) {
         io.valid_nxt[b * NT + tid] = -2; io.heavy_flag[b * NT + tid] = 0;
@@ -2203,16 +2206,16 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     G.cam.plx = cam.pixelLength.x; G.cam.ply = cam.pixelLength.y;
     G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix; G.late_stores = ws.gen_late;
     TraceIO io;
-    io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr;
+    io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr; io.inv_cur = cur.inv;
     io.pref = ws.seg_pref; io.first = ws.seg_first; io.hit_pref = ws.hit_pref; io.first_h = ws.seg_first_h;
-    io.nxt = nxt.paths; io.hnxt = nxt.hits; io.hr_nxt = nxt.hr;
+    io.nxt = nxt.paths; io.hnxt = nxt.hits; io.hr_nxt = nxt.hr; io.inv_nxt = nxt.inv;
     io.agg_s = ws.agg_b; io.agg_h = ws.agg_h;
     io.valid_nxt = ws.tr_valid; io.heavy_flag = ws.tr_heavy; io.heavy_agg = ws.agg_a;
-    // the launch that shades bounce dt - 1 reads counts[dt - 1]; its last block writes counts[dt] = the rays it traced.  COMPACT (hit-dense
-    // shading): it shades the hcounts[dt - 1] paths of bounce dt - 1 that hit something, and writes hcounts[dt] = the hits it found
-    const int* d_n = gen ? nullptr : (compact ? ws.hcounts : ws.counts) + (dt - 1);
+    // the launch that shades bounce dt - 1 reads counts[dt - 1]; its last block writes counts[dt] = the rays it traced.  Hit-dense shading (every
+    // layout but SPLIT): it shades the hcounts[dt - 1] paths of bounce dt - 1 that hit something, and writes hcounts[dt] = the hits it found
+    const int* d_n = gen ? nullptr : (!split ? ws.hcounts : ws.counts) + (dt - 1);
     const SegTail2 tail = {ws.seg_done, ws.seg_pref, ws.seg_first, split ? nullptr : ws.hit_pref, ws.counts + dt, last ? ws.iter_dev : nullptr, ws.iter_stride, ws.ray_total,
-                           compact ? ws.seg_first_h : nullptr, compact ? ws.hcounts + dt : nullptr};
+                           !split ? ws.seg_first_h : nullptr, !split ? ws.hcounts + dt : nullptr};
     const int depth = dt - 1;           // RNG key depth of the bounce being shaded
     mark(gen ? 0 : 2, true);
     int rc;
@@ -2263,7 +2266,9 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     if (hits0) S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;      // as the launch that wrote them
     A.iter_arg = iter; A.iter_ptr = ws.iter_dev; A.depth0 = depth0; A.trace_depth = trace_depth;
     A.counts = ws.counts; A.cur = cur; A.nxt = nxt;
-    A.nshaded = (depth0 > 0 ? ((A.compact && ws.hcounts) ? ws.hcounts : ws.counts) + (depth0 - 1) : ws.counts);
+    // the last full-width launch was a hit-dense k_shade_trace (every fused layout but SPLIT): its windows = ceil(hcounts[depth0 - 1] / 256)
+    const bool hit_dense = hits0 != nullptr && ws.hcounts && !(S_in.n_tris > 0 && !ws.inline_bvh && ws.queue && ws.list);
+    A.nshaded = (depth0 > 0 ? (hit_dense ? ws.hcounts : ws.counts) + (depth0 - 1) : ws.counts);
     const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
     A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
