@@ -402,7 +402,9 @@ def main():
                          "whole-frame work fixed, per-rank launches shrink by N); iteration_sharded (weak / strong): K*IPS / K*IPS/N "
                          "whole-frame iterations per rank"}
     if rank == 0:
-        fused = a.pipeline == 10 or (a.pipeline == 0 and scene.n_triangles == 0)      # what ptk_set_pipeline(0) picks (include/ptk.h)
+        # what ptk_set_pipeline(0) picks (include/ptk.h, pathtrace.hip use_trace_pipeline): the fused launches for triangle-free scenes, for meshes
+        # of up to 32 triangles (walked inside the kernel) and, on larger meshes, in MIS mode
+        fused = a.pipeline == 10 or (a.pipeline == 0 and (scene.n_triangles <= 32 or a.mode == "mis"))
         staged = 8 if fused else a.pipeline        # k_intersect on its own: the kernel SURVEY 8d's 76 B / ray figure is defined on
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, staged, a.profile_steps)
         roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)
@@ -478,7 +480,7 @@ def main():
                        "iterations_total": head["calls"] * (N if a.shard == "iterations" else 1) * spp,
                        "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
                        "pipeline": ("one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d (segmented streams, physical-slot hit records, window hit "
-                                    "prefixes); device-resident counts, no host sync") if (a.pipeline == 10 or (a.pipeline == 0 and scene.n_triangles == 0)) else
+                                    "prefixes); device-resident counts, no host sync") if fused else
                                    "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync",
                        "step_definition": "one step = iterations_per_step pathtrace() iterations (1 in round 1, 16 since round 2): compare ms_per_iteration across rounds, not ms_per_step"},
             "device_ms_per_step": round(dev_ms / a.steps, 4), "ms_per_iteration": round(1e3 * elapsed / (a.steps * IPS), 4),
@@ -496,7 +498,7 @@ def main():
             rec = pmc_record(a.scene) if (scene.width, scene.height) == (800, 800) and res is None and a.depth < 0 else None
             if rec:
                 per_iter = 0.0
-                per_launch = ({"k_shade_trace": scene.trace_depth, "k_shade_trace_gen": 1} if (a.pipeline == 10 or (a.pipeline == 0 and scene.n_triangles == 0)) else
+                per_launch = ({"k_shade_trace": scene.trace_depth, "k_shade_trace_gen": 1} if fused else
                               {"k_intersect": scene.trace_depth, "k_shade_binned": scene.trace_depth, "k_generate": 1})
                 for k, mult in per_launch.items():
                     c = (rec.get(k) or {}).get("counters") if isinstance(rec.get(k), dict) else None

@@ -224,14 +224,19 @@ int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
 /* Pipeline selection (A/B comparisons; all produce identical results):
- *   0 = default: 10 for scenes without triangles, 8 for scenes with (a BVH stage behind every launch leaves the fusion nothing to win:
- *       measured 1-3 % behind);
+ *   0 = default: the fused launches of 10 for scenes without triangles, for meshes of up to 32 triangles (the reference's walk then runs
+ *       inside the fused kernel's trace phase, per lane: no work list, one launch per bounce) and, on larger meshes, in MIS mode (its
+ *       shadow rays run in a balanced block phase); the staged kernels of 8 for larger meshes in BSDF / DIRECT mode (a BVH stage behind
+ *       every launch leaves the fusion nothing to win there: measured 1-3 % behind);
  *   10 = one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d for the
  *       survivors while their new rays are still in registers (the first launch of an iteration generates the camera rays
  *       instead of shading); path state and hit record are written together at the survivor's slot in its block's window, the
  *       compacted slot of a hit path (the reference's RNG key) is hit_pref[window] + its rank among the window's hits, and the last
  *       block of every launch builds the window tables.  Triangle-free scenes without textures use compact streams (four 16-byte
- *       records per path, five in MIS: only what shading really reads, with the rank and the material type in one word).  Scenes with triangles continue each launch with the work-list BVH stage
+ *       records per path, five in MIS: only what shading really reads).  Every layout without a BVH stage shades HIT-DENSE: a launch
+ *       enumerates the paths that hit something (the reference's compacted slot is the index itself) through the hit prefix and a per-window
+ *       inverse map the tracing block writes; a miss is never loaded again.  Next-event shadow rays (MIS / DIRECT) are tested in a block-cooperative
+ *       any-hit phase between shading and tracing.  Scenes with larger meshes continue each launch with the work-list BVH stage
  *       (stable compaction of the rays that enter the root box, BVH walk over the list, finalize).  While the traversal counters
  *       are enabled the staged kernels of 8 run instead (they keep the counters);
  *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the

@@ -278,7 +278,10 @@ bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 4 && g.pipeline != 
 // the staged kernels are 1-3 % ahead (bunny scene 5.70 vs 5.62 Grays/s); the traversal counters are only kept by the staged kernels
 bool use_trace_pipeline() {
     if (!trace_pipeline(g.pipeline) || (g.lanes.size() && g.lanes[0].ws.stats)) return false;
-    return g.pipeline == 10 || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline);      // (tiny mesh: walked inside the fused kernel)
+    if (g.pipeline == 10 || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline)) return true;      // (tiny mesh: walked inside the fused kernel)
+    // larger meshes: a BVH stage follows every launch either way.  The staged kernels are ahead in BSDF / DIRECT (bunny scene 5.93 vs 5.85, 7.8 vs
+    // 7.0 Grays/s); in MIS the fused kernel is, since its shadow rays run in a balanced phase at six waves per SIMD (5.69 vs 5.55)
+    return current_mode() == PTK_MODE_MIS;
 }
 void no_mark(int, bool) {}
 

@@ -7,7 +7,9 @@ sys.path.insert(0, ROOT)
 ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
 for scn, mode, iters, kw in (("cornell.txt", 0, 3000, dict(in_flight=3, graph=True)), ("mis_test.txt", 2, 3000, dict(in_flight=3, graph=True)),
                              ("bunny_cornell.txt", 2, 600, dict(in_flight=3, graph=True)), ("bunny_cornell.txt", 0, 300, dict(in_flight=1)),
-                             ("bunny_cornell.txt", 2, 600, dict(in_flight=3, graph=True, pipeline=10)), ("textureEnv_test.txt", 2, 400, dict(in_flight=3, graph=True, pipeline=10))):
+                             ("bunny_cornell.txt", 2, 600, dict(in_flight=3, graph=True, pipeline=10)), ("textureEnv_test.txt", 2, 400, dict(in_flight=3, graph=True, pipeline=10)),
+                             ("textureEnv_test.txt", 2, 400, dict(in_flight=3, graph=True)), ("obj_test.txt", 2, 600, dict(in_flight=3, graph=True)),
+                             ("mis_test2.txt", 1, 1000, dict(in_flight=3, graph=True))):
     imgs = []
     for rep in range(2):
         s = ptk.Scene(os.path.join(ROOT, "scenes", scn))
