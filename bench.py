@@ -23,9 +23,13 @@ time = MAX over ranks; value = rays of all ranks / time.  The scene, BVH and all
 timed region starts (nothing crosses PCIe inside it).
 
 Also on the JSON line:
-  roofline     : the dominant kernel (k_intersect) priced against the 8 TB/s HBM roofline with its ALGORITHMIC bytes
-                 (76 B/ray analytic; + 40 B per BVH node visit + 124 B per triangle test), its device time
-                 measured live with HIP events on the render stream in a separate, untimed profiling pass.
+  roofline     : the dominant kernel OF THE TIMED PIPELINE priced against the 8 TB/s HBM roofline with its ALGORITHMIC bytes, its device
+                 time measured live with HIP events on the render stream in a separate, untimed profiling pass.  Since round 3 the timed
+                 pipeline runs one fused launch per bounce, k_shade_trace (shade bounce d-1 + both compactions + trace bounce d): 224 B per
+                 path-bounce, SURVEY §8d's whole-bounce figure (intersect 76 + 2 x 8 + shade 132).  Scenes that run the staged kernels
+                 (larger meshes in BSDF / DIRECT) get k_intersect (+ the BVH stage) there instead.
+  roofline_k_intersect : the staged intersection kernel alone (pipeline 8), 76 B/ray analytic (+ 40 B per BVH node visit + 124 B per
+                 triangle test) — the ruler of rounds 1-2 (`roofline` then), kept so that the rounds stay comparable.
   cpu_baseline : the CPU oracle ("port", single thread) timed on rank 0's host on a bounded sample of the same workload.
 """
 import argparse
@@ -256,8 +260,15 @@ def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
     avg_us = 1e3 * ms / launches
     rp = rocprof_avg_us(scene_file, "k_shade_trace<0, false, false") if (scene.width, scene.height) == (800, 800) else None
     pm = ((pmc_record(scene_file) or {}).get("k_shade_trace") or {}) if (scene.width, scene.height) == (800, 800) else {}
-    return {"bound": "valu", "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    alg_per_launch = rays_p * BYTES_PER_PATH_BOUNCE / launches
+    return {"bound": "valu", "bound_note": "priced against the HBM roofline as the contract asks; measured (DESIGN.md section 5): with three iterations in flight the "
+                                           "vector ALUs are ~1.0 busy by the counters, the HBM carries ~0.5 of its peak and the LDS pipe ~0.4 — a balanced kernel "
+                                           "whose exact arithmetic (IEEE divide / sqrt, no contraction) sets the instruction count",
+            "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic_bytes_per_launch"),
+            "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE,
+            "frac_rocprof": round(alg_per_launch / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp else None,
+            "rocprof_note": "the same algorithmic bytes over k_shade_trace's average duration in the committed rocprofv3 summary of the single-stream configuration",
             "algorithmic_bytes_per_launch": round(rays_p * BYTES_PER_PATH_BOUNCE / launches), "bytes_per_path_bounce": BYTES_PER_PATH_BOUNCE,
             "rays_per_launch": round(rays_p / launches, 1), "avg_launch_us": round(avg_us, 2), "avg_launch_us_rocprof": round(rp, 2) if rp else None,
             "counters": pm.get("counters"),
@@ -411,8 +422,10 @@ def main():
         extra = {}
         if fused:
             pf = measure_kernels(ptk, scene, mode, 10, a.profile_steps)
-            extra["roofline_dominant"] = roofline_fused(scene, pf[0], pf[1], a.profile_steps, a.scene)
-            extra["roofline_valu_dominant"] = roofline_valu(a.scene, extra["roofline_dominant"])
+            # `roofline` = the dominant kernel of the pipeline that was timed; the staged k_intersect keeps its own key (rounds 1-2's `roofline`)
+            extra["roofline_k_intersect"] = roofline
+            extra["roofline_valu_k_intersect"] = roofline_valu(a.scene, roofline)
+            roofline = roofline_fused(scene, pf[0], pf[1], a.profile_steps, a.scene) or roofline
         extra["roofline_valu"] = roofline_valu(a.scene, roofline)
         if N == 1 and not a.lean and a.bvh_scene and a.bvh_scene != a.scene:
             # the HBM-fraction target is only meaningful where the kernel streams BVH data: same measurement
@@ -459,7 +472,7 @@ def main():
                 cj = json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
                 pm = (pmc_record(a.scene) or {}).get("contracted_fma") or {}
                 contracted = {"value": cj["value"], "unit": "Mrays/s", "ms_per_iteration": cj["ms_per_iteration"], "frac": cj["roofline"]["frac"],
-                              "frac_note": "k_intersect, same algorithmic bytes / HIP-event launch time as roofline.frac",
+                              "frac_note": "same kernel, algorithmic bytes and HIP-event launch time as roofline.frac",
                               "valu_per_wave": pm.get("valu_per_launched_wave"), "valu_per_wave_exact": pm.get("valu_per_launched_wave_exact"),
                               "flavour": cj.get("flavour"),
                               "note": "libptk_fma.so = the same sources with -ffp-contract=fast (IEEE divide / sqrt kept); not bit-comparable with the oracle, "
