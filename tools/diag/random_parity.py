@@ -1,7 +1,7 @@
 """GPU box: randomised parity sweep (diagnostic, beyond the fixed cases of tests/).  Random analytic scenes — a room with a random subset
 of its walls (open and closed scenes), 3-60 random cubes / spheres (rotated, overlapping), materials of all five types, sphere and cube
 lights — rendered in a random mode with random resolution, depth, iterations in flight, graph replay, tile partition and samples per launch;
-image and live counts of every iteration must equal the CPU oracle's bit for bit.   usage: random_parity.py [n_cases] [first_seed]"""
+image and live counts of every iteration must equal the CPU oracle's bit for bit.   usage: [MESHES=1] random_parity.py [n_cases] [first_seed]   (MESHES=1 adds 1-3 OBJ meshes — cube / sphere / bunny — to most scenes)"""
 import importlib, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
 import oracle_lib as orc
 orc.set_trig_mode(orc.TRIG_PTK)
+MESHES = int(os.environ.get("MESHES", "0"))
 try: orc.set_threads(min(16, os.cpu_count() or 1))
 except Exception: pass
 
@@ -41,6 +42,14 @@ def scene_text(rng):
         kind = "cube" if rng.uniform() < 0.5 else "sphere"
         mat = f"m{int(rng.integers(0, n_mats))}" if rng.uniform() < 0.93 else f"l{int(rng.integers(0, max(n_lights, 1)))}"
         objs.append((kind, mat, tuple(rng.uniform([-5, 0.5, -5], [5, 9, 4])), tuple(rng.uniform(0, 90, 3) * (rng.uniform() < 0.5)), tuple(rng.uniform(0.3, 2.2, 3))))
+    # meshes (MESHES=1): cube.obj (12 triangles: up to two of them stay inside the fused kernel's inline walk), sphere.obj (320), bunny10k.obj —
+    # sometimes with a light material (triangle lights: light_sample / light_pdf on triangles)
+    if MESHES and rng.uniform() < 0.8:
+        for k in range(int(rng.integers(1, 4))):
+            f, scale = [("cube.obj", rng.uniform(0.8, 2.5)), ("sphere.obj", rng.uniform(0.5, 1.5)), ("bunny10k.obj", rng.uniform(2, 5))][int(rng.choice([0, 0, 1, 2]))]
+            mat = f"m{int(rng.integers(0, n_mats))}" if rng.uniform() < 0.8 else f"l{int(rng.integers(0, max(n_lights, 1)))}"
+            objs.append((os.path.join(ROOT, "scenes", "model", f), mat, tuple(rng.uniform([-3.5, 0.5, -3.5], [3.5, 6, 2.5])), tuple(rng.uniform(0, 360, 3) * (rng.uniform() < 0.6)),
+                         tuple(np.repeat(scale, 3))))
     for i, (kind, mat, pos, rot, sc) in enumerate(objs):
         L += [f"OBJECT o{i}", kind, f"material {mat}", "TRANS %.6g %.6g %.6g" % tuple(pos), "ROTAT %.6g %.6g %.6g" % tuple(rot), "SCALE %.6g %.6g %.6g" % tuple(sc), ""]
     return "\n".join(L) + "\n", (W, H, depth, len(objs), n_lights)
@@ -54,7 +63,7 @@ def one_case(seed, tmp):
     part = (1, 0, 1); spp = 1
     if rng.uniform() < 0.3:
         n = int(rng.integers(2, 5)); part = (n, int(rng.integers(0, n)), int(rng.choice([1, 4, 8]))); spp = int(rng.integers(1, 4))
-    pipeline = int(rng.choice([0, 0, 0, 10, 8]))
+    pipeline = int(rng.choice([0, 0, 0, 10, 8, 1] if MESHES else [0, 0, 0, 10, 8]))
     iters = int(rng.integers(3, 13))
     s = ptk.Scene(path); o = orc.Scene(path)
     kw = dict(in_flight=lanes, graph=graph, pipeline=pipeline)
