@@ -414,8 +414,8 @@ def main():
                          "whole-frame iterations per rank"}
     if rank == 0:
         # what ptk_set_pipeline(0) picks (include/ptk.h, pathtrace.hip use_trace_pipeline): the fused launches for triangle-free scenes, for meshes
-        # of up to 32 triangles (walked inside the kernel) and, on larger meshes, in MIS mode
-        fused = a.pipeline == 10 or (a.pipeline == 0 and (scene.n_triangles <= 32 or a.mode == "mis"))
+        # of up to 1 024 triangles (walked inside the kernel) and, on larger meshes, in MIS mode
+        fused = a.pipeline == 10 or (a.pipeline == 0 and (scene.n_triangles <= 1024 or a.mode == "mis"))
         staged = 8 if fused else a.pipeline        # k_intersect on its own: the kernel SURVEY 8d's 76 B / ray figure is defined on
         prof, rays_p, counts_p, nodes, tris, rays_s = measure_kernels(ptk, scene, mode, staged, a.profile_steps)
         roofline = roofline_of(scene, prof, rays_p, counts_p, nodes, tris, rays_s, a.profile_steps, a.scene)

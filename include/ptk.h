@@ -224,7 +224,7 @@ int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
 /* Pipeline selection (A/B comparisons; all produce identical results):
- *   0 = default: the fused launches of 10 for scenes without triangles, for meshes of up to 32 triangles (the reference's walk then runs
+ *   0 = default: the fused launches of 10 for scenes without triangles, for meshes of up to 1 024 triangles in all (the reference's walk then runs
  *       inside the fused kernel's trace phase, per lane: no work list, one launch per bounce) and, on larger meshes, in MIS mode (its
  *       shadow rays run in a balanced block phase); the staged kernels of 8 for larger meshes in BSDF / DIRECT mode (a BVH stage behind
  *       every launch leaves the fusion nothing to win there: measured 1-3 % behind);

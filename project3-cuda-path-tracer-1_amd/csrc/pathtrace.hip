@@ -142,14 +142,18 @@ static int pick_walk(int pipeline, int n_lanes) {
 }
 
 // The BVH walk inside the intersect kernel (pipelines 1 / 2) instead of the work-list stage (k_list + k_traverse_wide + k_finalize): three
-// launches fewer per bounce, which is what a mesh of a dozen triangles costs in the first place.  Pipeline 0 picks it for tiny meshes, and
-// then runs the fused launches with the walk in their trace phase (one launch per bounce) — measured on the BASELINE configs[2] scene
-// obj_test.txt (cube.obj, 12 triangles): staged + work list 11.07, staged + inline walk 12.95, fused + inline walk 14.14 Grays/s;
-// sphere.obj (320 triangles) is already far on the other side (inline 15.3 vs work list 37.0).  Identical results.
-constexpr int kInlineBvhMaxTris = 32;
+// launches fewer per bounce.  Pipeline 0 picks it for small meshes, and then runs the fused launches with the walk in their trace phase (one
+// launch per bounce).  Measured (tools/diag/inline_threshold.py, Grays/s, BSDF / MIS, work list vs in-kernel walk): obj_test.txt (cube.obj, 12
+// triangles, BASELINE configs[2]) staged + work list 11.1, staged + inline walk 12.9, fused + inline walk 14.1; the same room with K scattered
+// meshes: 36 triangles 10.7 / 9.2 vs 13.8 / 12.9; 288: 5.7 / 5.2 vs 6.6 / 6.5; 320 (sphere.obj): 8.2 / 7.4 vs 8.9 / 8.3; 1 280: 4.7 / 4.5 vs
+// 5.1 / 4.9; 5 120: 2.9 / 2.8 vs 3.0 / 3.0 — and the other way round for ONE dense mesh that most rays enter (bunny scene, 10 000 triangles):
+// 5.96 / 5.62 vs 4.69 / 4.20.  The triangle count is a crude stand-in for "how many rays walk deep"; 1 024 keeps every measured win and stays
+// clear of the bunny class.  Identical results either way (PTK_INLINE_BVH_MAX_TRIS overrides it for A/B runs).
+constexpr int kInlineBvhMaxTris = 1024;
 bool inline_bvh_choice(int which) {
     if (which == 1 || which == 2) return true;
-    return which == 0 && g.scene && g.scene->tempDevScene.tri_num > 0 && g.scene->tempDevScene.tri_num <= kInlineBvhMaxTris;
+    static const int max_tris = getenv("PTK_INLINE_BVH_MAX_TRIS") ? atoi(getenv("PTK_INLINE_BVH_MAX_TRIS")) : kInlineBvhMaxTris;      // (A/B knob)
+    return which == 0 && g.scene && g.scene->tempDevScene.tri_num > 0 && g.scene->tempDevScene.tri_num <= max_tris;
 }
 
 int lane_init(Lane& l, int idx) {
