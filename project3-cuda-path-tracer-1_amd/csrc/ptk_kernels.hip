@@ -1498,15 +1498,17 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             // compacted slot, the RNG key, itself.  A miss is never shaded (h.t <= 0: colour 0, no radiance, dead), so it is never even loaded: an
             // open scene (mis_test.txt: 200 435 hits among 1 048 576 camera rays, 4 953 among the 196 540 rays of bounce 1) runs 783 + 20 full
             // blocks instead of 4 096 + 768 mostly idle ones.  Hit index -> window by the hit prefix (five scalar loads, first_h[b] = the
-            // window of hit 256 b); hit r of window w sits at the slot the tracing block recorded in inv[256 w + r] (with the material type,
-            // the sort key).  Survivors keep their order, so every later key is unchanged.
+            // window of hit 256 b); hit r of window w sits at the slot the tracing block recorded as the window's r-th inverse-map word (with
+            // the material type, the sort key): in the normal's spare word of slot 256 w + r (compact streams) or in inv[256 w + r].
+            // Survivors keep their order, so every later key is unchanged.
             const int w0 = io.first_h[b];
             const int h0 = io.hit_pref[w0], h1 = io.hit_pref[w0 + 1], h2 = io.hit_pref[w0 + 2], h3 = io.hit_pref[w0 + 3], h4 = io.hit_pref[w0 + 4];
             if (i < n) {
                 int k = (i >= h1) + (i >= h2) + (i >= h3) + (i >= h4);
                 int base = k == 0 ? h0 : (k == 1 ? h1 : (k == 2 ? h2 : (k == 3 ? h3 : h4)));
                 if (k == 4) k = sparse_window(io.hit_pref, w0 + 4, nw_prev, i, base) - w0;
-                const int word = io.inv_cur[(w0 + k) * NT + (i - base)];
+                const int at = (w0 + k) * NT + (i - base);
+                const int word = COMPACT ? (__float_as_int(io.hcur.t_n[4 * (size_t)at + 3]) & 0x7fffffff) : io.inv_cur[at];      // compact streams: in the normal's spare word
                 src_mine = (w0 + k) * NT + (word & 0xff);
                 flag = 1; key = word >> 8; slot_mine = i + slot_bias;
             }
@@ -1691,14 +1693,19 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             __syncthreads();
             if (tid == 0) { int t = 0; for (int w = 0; w < NW; ++w) t += s_red[w]; io.heavy_agg[b] = t; }
         } else if (COMPACT) {
-            // hit record with the rank in the normal's spare word: only the slots of survivors are written (nobody reads the others)
+            // The normal's spare word of slot p carries TWO things: its sign says whether slot p itself missed (k_tail reads that when it takes
+            // over after this launch), its low bits are the window's inverse map for hit-dense shading — hit number p of this window sits at
+            // slot (word & 0xff), material type (word >> 8) & 0x7f — handed from the thread that owns that hit through LDS (the ds_min keys are
+            // dead since the barrier above).  No stream of its own: the next launch's head reads the very lines it loads the normals from.
+            const int rank_h = before + __popcll(hb & lt), type = flag ? S.mats[h.mat].type : 0;
+            int* s_inv = reinterpret_cast<int*>(s_best);
+            if (active && flag) s_inv[rank_h] = tid | (type << 8);
+            __syncthreads();
             if (active) {
-                const int rank_h = before + __popcll(hb & lt), type = flag ? S.mats[h.mat].type : 0;
-                const int word = flag ? (rank_h | (type << 8)) : -1;      // rank < 256; k_tail reads the sign (hit / miss) when it takes over after this launch
+                const int word = (tid < hits ? s_inv[tid] : 0) | (flag ? 0 : (int)0x80000000u);
                 st4(io.hnxt.t_n, slot, make_float4(h.n.x, h.n.y, h.n.z, __int_as_float(word)));
                 if (flag) {
                     st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(MODE == PTK_MODE_MIS ? h.geom : h.mat)));
-                    io.inv_nxt[b * NT + rank_h] = tid | (type << 8);     // inv: hit r of this window -> its slot, and the next launch's sort key
                     if (GEN && gen_late) {                               // (thread tid generated and traced camera ray `slot`)
                         st4(io.nxt.o_pix, slot, make_float4(rd.x, rd.y, rd.z, __int_as_float(gen_pixw)));
                         st4(io.nxt.d_bnc, slot, make_float4(1.f, 1.f, 1.f, __int_as_float(gen.trace_depth)));
