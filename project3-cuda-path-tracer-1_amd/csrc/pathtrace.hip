@@ -33,7 +33,6 @@ struct Lane {
     PtkPaths bufA = {nullptr, nullptr, nullptr}, bufB = {nullptr, nullptr, nullptr};
     PtkHits hits = {nullptr, nullptr, nullptr}, hitsB = {nullptr, nullptr, nullptr};     // hitsB, hrA/hrB: fused pipeline (hit records ping-pong with the paths)
     int* hrA = nullptr; int* hrB = nullptr;
-    int* invA = nullptr; int* invB = nullptr;     // hit-dense shading: per-window inverse maps (hit r -> slot | type << 8), ping-pong with the streams
     Workspace ws;
     float* plane = nullptr;             // float[3*P] radiance sum of this lane's iterations (points into RenderContext::planes)
     int last_iter = 0;
@@ -100,7 +99,7 @@ int context_free() {
     for (Lane& l : g.lanes) {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
-        dfree(l.hitsB.t_n); dfree(l.hitsB.p_mat); dfree(l.hitsB.uv_ids); dfree(l.hrA); dfree(l.hrB); dfree(l.invA); dfree(l.invB);
+        dfree(l.hitsB.t_n); dfree(l.hitsB.p_mat); dfree(l.hitsB.uv_ids); dfree(l.hrA); dfree(l.hrB);
         dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy); dfree(l.ws.hcounts); dfree(l.ws.seg_first_h);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
@@ -179,8 +178,6 @@ int lane_init(Lane& l, int idx) {
     const size_t slots = ((size_t)g.capacity + 255) / 256 * 256 + 256;          // physical slots: whole 256-slot windows
     if ((rc = dalloc(&l.hrA, slots))) return rc;
     if ((rc = dalloc(&l.hrB, slots))) return rc;
-    if ((rc = dalloc(&l.invA, slots))) return rc;
-    if ((rc = dalloc(&l.invB, slots))) return rc;
     if ((rc = dalloc(&l.ws.tr_valid, slots))) return rc;
     if ((rc = dalloc(&l.ws.tr_heavy, slots))) return rc;
     const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;
@@ -301,7 +298,7 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     if (use_trace_pipeline()) {
         // launch 0 generates the camera rays and traces bounce 0; launch dt shades bounce dt - 1 and traces bounce dt (k_shade_trace)
         void (*mark)(int, bool) = g_prof.on ? prof_mark : no_mark;
-        TraceBufs A = {L.bufA, L.hits, L.hrA, L.invA}, B = {L.bufB, L.hitsB, L.hrB, L.invB};
+        TraceBufs A = {L.bufA, L.hits, L.hrA}, B = {L.bufB, L.hitsB, L.hrB};
         TraceBufs *cur = &A, *nxt = &B;
         int rc = launch_shade_trace(S, mode, true, cam, g.n_parts, g.part, g.tile_rows, g.n_pix, g.traceDepth, iter, 0, g.capacity, A, A, L.plane, ws, L.stream, false, mark);
         for (int dt = 1; dt <= full && !rc; ++dt) {

@@ -82,7 +82,7 @@ int launch_bounce_staged_profiled(const SceneView& S, int mode, int iter, int de
 int launch_tail(const SceneView& S, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,
                 const Workspace& ws, hipStream_t st, const PtkHits* hits0 = nullptr, const int* hr0 = nullptr);
 // fused pipeline (k_shade_trace): shade bounce dt - 1 of `cur` (gen: generate the camera rays instead) and trace bounce dt into `nxt`
-struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; int* inv; };
+struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; };
 int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool));

@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
     } else if (flag == 1) mat = __float_as_int(hits.p_mat[4 * (size_t)i + 3]);      // analytic winner: record written by k_shade_trace
     int total;
     const int rank = block_excl_prefix(flag >= 1 ? 1 : 0, total);
-    hr[i] = flag >= 1 ? (rank | (S.mats[mat].type << 8)) : (flag == 0 ? -1 : -2);      // rank | material type << 8: the next launch's head reads one word
+    hr[i] = flag >= 1 ? (rank | (S.mats[mat].type << 8)) : (flag == 0 ? (int)0x80000000u : (int)0xC0000000u);      // rank | material type << 8: the next launch's head reads one word; top bits 10 = miss, 11 = empty slot
     // the last block to get here builds hit_pref (two-level done counters as in segments_tail; they are back at zero after every launch)
     __shared__ int s_last;
     const int nb = (n + PTK_BLOCK - 1) / PTK_BLOCK, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
@@ -816,12 +816,12 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
     for (int k = threadIdx.x; k <= ng; k += PTK_BLOCK) __hip_atomic_store(done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     (void)prefix_block<PTK_BLOCK, true>(nb, agg_h, hit_pref);
 }
-// environment map on a miss, fused pipeline: slot g of the traced stream missed iff hr[g] == -1
+// environment map on a miss, fused pipeline: slot g of the traced stream missed iff the top bits of hr[g] are 10 (00: hit, 11: empty slot)
 __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths, const int* __restrict__ hr,
                                                           float* __restrict__ img, unsigned plane_stride) {
     const int n = d_n ? *d_n : n_arg;
     const int g = blockIdx.x * PTK_BLOCK + threadIdx.x;
-    if (blockIdx.x * PTK_BLOCK >= n || hr[g] != -1) return;
+    if (blockIdx.x * PTK_BLOCK >= n || ((unsigned)hr[g] >> 30) != 2u) return;      // status bits 10 = a traced ray that missed
     const float4 d4 = ld4(paths.d_bnc, g), c4 = ld4(paths.col_pdf, g);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)g + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
@@ -1263,10 +1263,10 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
 // ------------------------------------------------------------------------------------------------------------------
 struct TraceIO {
     // the bounce being shaded (unused with GEN): paths, their hit records and hit ranks at PHYSICAL slots, the window tables
-    PtkPaths cur; PtkHits hcur; const int* hr_cur; const int* inv_cur;      // inv: hit r of window w -> slot | type << 8 (hit-dense shading, every layout but SPLIT)
+    PtkPaths cur; PtkHits hcur; const int* hr_cur;      // hr: the slot's status + (hit-dense shading) the window's inverse map, full-width layouts
     const int* pref; const int* first; const int* hit_pref; const int* first_h;      // first_h: COMPACT (hit-dense shading)
     // the bounce being traced: survivors (or fresh camera rays), their hit records and ranks
-    PtkPaths nxt; PtkHits hnxt; int* hr_nxt; int* inv_nxt;
+    PtkPaths nxt; PtkHits hnxt; int* hr_nxt;
     int* agg_s; int* agg_h;              // per-window survivor / hit counts of this launch
     int* valid_nxt;                      // SPLIT: 0 / 1 / -2 per slot for k_traverse / k_finalize
     int* heavy_flag; int* heavy_agg;     // SPLIT: rays that enter the BVH root box
@@ -1499,7 +1499,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             // open scene (mis_test.txt: 200 435 hits among 1 048 576 camera rays, 4 953 among the 196 540 rays of bounce 1) runs 783 + 20 full
             // blocks instead of 4 096 + 768 mostly idle ones.  Hit index -> window by the hit prefix (five scalar loads, first_h[b] = the
             // window of hit 256 b); hit r of window w sits at the slot the tracing block recorded as the window's r-th inverse-map word (with
-            // the material type, the sort key): in the normal's spare word of slot 256 w + r (compact streams) or in inv[256 w + r].
+            // the material type, the sort key): in the normal's spare word of slot 256 w + r (compact streams) or in the hr word of that slot.
             // Survivors keep their order, so every later key is unchanged.
             const int w0 = io.first_h[b];
             const int h0 = io.hit_pref[w0], h1 = io.hit_pref[w0 + 1], h2 = io.hit_pref[w0 + 2], h3 = io.hit_pref[w0 + 3], h4 = io.hit_pref[w0 + 4];
@@ -1508,7 +1508,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 int base = k == 0 ? h0 : (k == 1 ? h1 : (k == 2 ? h2 : (k == 3 ? h3 : h4)));
                 if (k == 4) k = sparse_window(io.hit_pref, w0 + 4, nw_prev, i, base) - w0;
                 const int at = (w0 + k) * NT + (i - base);
-                const int word = COMPACT ? (__float_as_int(io.hcur.t_n[4 * (size_t)at + 3]) & 0x7fffffff) : io.inv_cur[at];      // compact streams: in the normal's spare word
+                const int word = (COMPACT ? __float_as_int(io.hcur.t_n[4 * (size_t)at + 3]) : io.hr_cur[at]) & 0x3fffffff;      // in the normal's spare word / the hr word
                 src_mine = (w0 + k) * NT + (word & 0xff);
                 flag = 1; key = word >> 8; slot_mine = i + slot_bias;
             }
@@ -1715,9 +1715,14 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             }
         } else {
             // (textures / ENV map / a tiny mesh walked in this kernel: the full-width streams.  hr: the slot's own status for k_env_miss2 and k_tail)
+            // The hr word of slot p does double duty like the compact streams' spare word: bits 31-30 = the slot's own status (00 hit, 10 miss,
+            // 11 empty: k_env_miss2 and k_tail read them), the low bits = the window's inverse map for hit-dense shading (hit number p of the
+            // window sits at slot (word & 0xff), material type (word >> 8) & 0x7f), handed over through LDS.
             const int rank_h = before + __popcll(hb & lt), type = flag ? S.mats[h.mat].type : 0;
-            io.hr_nxt[slot] = active ? (flag ? (rank_h | (type << 8)) : -1) : -2;
-            if (flag) io.inv_nxt[b * NT + rank_h] = tid | (type << 8);
+            int* s_inv = reinterpret_cast<int*>(s_best);
+            if (active && flag) s_inv[rank_h] = tid | (type << 8);
+            __syncthreads();
+            io.hr_nxt[slot] = (tid < hits ? s_inv[tid] : 0) | (active ? (flag ? 0 : (int)0x80000000u) : (int)0xC0000000u);
         }
     } else if (SPLIT) {
         io.valid_nxt[b * NT + tid] = -2; io.heavy_flag[b * NT + tid] = 0;
@@ -2213,9 +2218,9 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     G.cam.plx = cam.pixelLength.x; G.cam.ply = cam.pixelLength.y;
     G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix; G.late_stores = ws.gen_late;
     TraceIO io;
-    io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr; io.inv_cur = cur.inv;
+    io.cur = cur.paths; io.hcur = cur.hits; io.hr_cur = cur.hr;
     io.pref = ws.seg_pref; io.first = ws.seg_first; io.hit_pref = ws.hit_pref; io.first_h = ws.seg_first_h;
-    io.nxt = nxt.paths; io.hnxt = nxt.hits; io.hr_nxt = nxt.hr; io.inv_nxt = nxt.inv;
+    io.nxt = nxt.paths; io.hnxt = nxt.hits; io.hr_nxt = nxt.hr;
     io.agg_s = ws.agg_b; io.agg_h = ws.agg_h;
     io.valid_nxt = ws.tr_valid; io.heavy_flag = ws.tr_heavy; io.heavy_agg = ws.agg_a;
     // the launch that shades bounce dt - 1 reads counts[dt - 1]; its last block writes counts[dt] = the rays it traced.  Hit-dense shading (every
