@@ -161,7 +161,7 @@ int lane_init(Lane& l, int idx) {
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
-    if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * ((size_t)g.traceDepth + 2 + 1), hipHostMallocDefault)) != hipSuccess) return (int)e;      // + hcounts[0]
+    if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * 2 * ((size_t)g.traceDepth + 2), hipHostMallocDefault)) != hipSuccess) return (int)e;      // counts, then hcounts
     l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
     l.ws.plane_stride = g.spp > 1 ? 3u * (unsigned)g.P : 0u;      // 0: no sample-plane bits in pixelIndex (pixel_ptr, ptk_kernels.hip)
     l.ws.spp = g.spp;
@@ -284,6 +284,10 @@ bool use_trace_pipeline() {
     // 7.0 Grays/s); in MIS the fused kernel is, since its shadow rays run in a balanced phase at six waves per SIMD (5.69 vs 5.55)
     return current_mode() == PTK_MODE_MIS;
 }
+// the fused launches shade hit-dense unless a BVH stage follows them (SPLIT: meshes too large for the in-kernel walk)
+bool hit_dense_pipeline() {
+    return use_trace_pipeline() && !(g.scene->tempDevScene.tri_num > 0 && !inline_bvh_choice(g.pipeline));
+}
 void no_mark(int, bool) {}
 
 int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
@@ -340,10 +344,13 @@ constexpr int kTailPaths = 1024;                 // a bounce with at most this m
 void note_counts(Lane& L) {
     if (!L.counts_pending || hipEventQuery(L.counts_ev) != hipSuccess) return;
     L.counts_pending = false;
+    // what k_tail looks at in its first bounce: the live paths — or, after a hit-dense launch, only the paths that hit something (mis_test.txt:
+    // 1 088 live but 43 hits at bounce 2: the tail takes over one 20-us launch earlier)
+    const int* cnt = hit_dense_pipeline() ? L.h_counts + g.traceDepth + 2 : L.h_counts;
     int d_new = g.traceDepth;
-    for (int d = 1; d < g.traceDepth; ++d) if (L.h_counts[d] <= kTailPaths) { d_new = d; break; }
+    for (int d = 1; d < g.traceDepth; ++d) if (cnt[d] <= kTailPaths) { d_new = d; break; }
     // hysteresis: widen at once, narrow only when the count is clearly below the threshold (no graph re-capture ping-pong)
-    if (d_new > g.full_bounces || (d_new < g.full_bounces && L.h_counts[d_new] <= kTailPaths / 2)) g.full_bounces = d_new;
+    if (d_new > g.full_bounces || (d_new < g.full_bounces && cnt[d_new] <= kTailPaths / 2)) g.full_bounces = d_new;
     // camera rays that hit something / camera rays (fused pipeline, compact streams): below ~half, the camera launch stores the path state of
     // the hits only, after its trace phase (k_shade_trace, GenArgs::late_stores); hysteresis as above.  Results never depend on it.
     const long long n0 = L.h_counts[0], h0 = L.h_counts[g.traceDepth + 2];
@@ -358,7 +365,7 @@ int request_counts(Lane& L) {
     if (++L.fresh_hint > 8 && L.fresh_hint % 16 != 0) return 0;
     hipError_t e = hipMemcpyAsync(L.h_counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
     if (e != hipSuccess) return (int)e;
-    if ((e = hipMemcpyAsync(L.h_counts + g.traceDepth + 2, L.ws.hcounts, sizeof(int), hipMemcpyDeviceToHost, L.stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemcpyAsync(L.h_counts + g.traceDepth + 2, L.ws.hcounts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream)) != hipSuccess) return (int)e;
     if ((e = hipEventRecord(L.counts_ev, L.stream)) != hipSuccess) return (int)e;
     L.counts_pending = true;
     return 0;

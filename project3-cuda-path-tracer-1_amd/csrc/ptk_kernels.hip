@@ -1810,6 +1810,10 @@ struct TailArgs {
     // fused pipeline: bounce depth0 has been traced already (k_shade_trace); its hit records / ranks sit at the paths' physical slots
     PtkHits hits0; const int* hr0; int have_hits;
     int compact;                             // ... in k_shade_trace's compact stream layout
+    // ... by a HIT-DENSE launch (every fused layout but SPLIT): the tail enumerates the hits of bounce depth0 like that launch's successor would
+    // (hit prefix + first_h + the inverse-map words), never its misses — and takes over as soon as a bounce has few HITS, however many rays
+    int hit_dense; const int* hit_pref; const int* first_h; const int* nhits;
+    int* hcounts;                            // (may be null) hcounts[d] = hits of bounce d, kept up to date for the host's hand-over hint
 };
 
 template <int MODE>
@@ -1823,10 +1827,11 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
     const Film img = {A.img, A.plane_stride};
     PtkPaths cur = A.cur, nxt = A.nxt;
     Gather G = A.G;
-    int n = A.counts[A.depth0];
+    int n = A.hit_dense ? *A.nhits : A.counts[A.depth0];        // paths to look at in the first bounce: its hits (hit-dense) or its live paths
     for (int depth = A.depth0; depth < A.trace_depth; ++depth) {
         if (n <= 0) {                                            // nothing left: the remaining bounces are empty
             for (int d = depth + 1 + threadIdx.x; d <= A.trace_depth; d += NT) A.counts[d] = 0;
+            if (A.hcounts) for (int d = depth + threadIdx.x; d <= A.trace_depth; d += NT) if (!(A.have_hits && d == A.depth0)) A.hcounts[d] = 0;
             break;
         }
         int hits_before = 0, survivors = 0;
@@ -1839,8 +1844,19 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
             h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
             p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
             if (i < n) {
-                const int src = gather_source(G, i / PTK_BLOCK, i, n, G.pref ? (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK : 0);
                 const bool traced = A.have_hits && depth == A.depth0;      // by the last full-width launch (ENV radiance of its misses added there)
+                int src;
+                if (traced && A.hit_dense) {
+                    // hit i of the traced bounce -> window (hit prefix) -> slot (inverse-map word of the window's (i - base)-th slot)
+                    const int nw = (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK;
+                    const int w0 = A.first_h[i / PTK_BLOCK];
+                    int k = 0, base = A.hit_pref[w0];
+                    while (k < 4 && i >= A.hit_pref[w0 + k + 1]) { ++k; base = A.hit_pref[w0 + k]; }
+                    if (k == 4) k = sparse_window(A.hit_pref, w0 + 4, nw, i, base) - w0;
+                    const int at = (w0 + k) * PTK_BLOCK + (i - base);
+                    const int word = (A.compact ? __float_as_int(A.hits0.t_n[4 * (size_t)at + 3]) : A.hr0[at]) & 0x3fffffff;
+                    src = (w0 + k) * PTK_BLOCK + (word & 0xff);
+                } else src = gather_source(G, i / PTK_BLOCK, i, n, G.pref ? (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK : 0);
                 if (traced && A.compact) {                                  // k_shade_trace's compact streams: (d, pix) (col, bounces) (n, rank) (p, mat)
                     const float4 a4 = ld4(cur.o_pix, src), b4 = ld4(cur.d_bnc, src), h0 = ld4(A.hits0.t_n, src);
                     p.pix = __float_as_int(a4.w); p.d = mk3(a4.x, a4.y, a4.z); p.bounces = __float_as_int(b4.w);
@@ -1889,6 +1905,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
         }
         if (threadIdx.x == 0) {
             A.counts[depth + 1] = survivors;
+            if (A.hcounts && !(A.have_hits && depth == A.depth0)) A.hcounts[depth] = hits_before;      // (the traced bounce's count was written by its launch)
             if (A.ray_total && !(A.have_hits && depth == A.depth0)) atomicAdd(A.ray_total, (unsigned long long)n);     // (counted by the launch that traced it)
         }
         __syncthreads();                                         // this bounce's stores are visible to the whole workgroup before the next bounce reads them
@@ -2281,6 +2298,8 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     // the last full-width launch was a hit-dense k_shade_trace (every fused layout but SPLIT): its windows = ceil(hcounts[depth0 - 1] / 256)
     const bool hit_dense = hits0 != nullptr && ws.hcounts && !(S_in.n_tris > 0 && !ws.inline_bvh && ws.queue && ws.list);
     A.nshaded = (depth0 > 0 ? (hit_dense ? ws.hcounts : ws.counts) + (depth0 - 1) : ws.counts);
+    A.hit_dense = (hit_dense && depth0 > 0) ? 1 : 0; A.hit_pref = ws.hit_pref; A.first_h = ws.seg_first_h; A.nhits = ws.hcounts ? ws.hcounts + depth0 : nullptr;
+    A.hcounts = ws.hcounts;
     const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
     A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
