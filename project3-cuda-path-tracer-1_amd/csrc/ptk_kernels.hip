@@ -1380,7 +1380,8 @@ __device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, con
 // COMPACT (triangle-free scenes without textures, BSDF / DIRECT modes): 64 B per path instead of 84.  Shading never reads the ray origin or
 // prevPdf outside MIS (lightPDF, pathtrace.cu:547-554) nor the hit distance beyond its sign, and (uv, geomID, triangleID) only with textures
 // or MIS — so the four 16-byte streams are  paths.o_pix = (direction, pixelIndex), paths.d_bnc = (color, remainingBounces),
-// hits.t_n = (normal, hit rank: the `hr` word), hits.p_mat = (point, materialId); col_pdf, uv_ids and the hr array stay untouched.
+// hits.t_n = (normal, word), hits.p_mat = (point, materialId); col_pdf, uv_ids and the hr array stay untouched.  `word` of slot p: sign = slot p
+// itself missed; low bits = the window's inverse map for hit-dense shading (hit number p of the window: its slot | material type << 8).
 // MIS adds a fifth stream, paths.col_pdf = (origin, prevPdf), and stores the primitive instead of the material in hits.p_mat.w (lightPDF needs
 // geomID; the material id is a field of the primitive's staged record; triangleID is -1 without triangles): 80 B per path instead of 100.
 // The timed configuration is partly bound by HBM traffic (+32 B per path costs 5.7 %, measured): −24 % bytes per path-bounce.
