@@ -135,6 +135,11 @@ static bool fold_segments(int pipeline, int n_lanes) {
     if (pipeline == 8 || trace_pipeline(pipeline)) return true;
     return n_lanes > 1;
 }
+static int pick_lpr(int n_lanes) {
+    static const int forced = getenv("PTK_WIDE_LPR") ? atoi(getenv("PTK_WIDE_LPR")) : 0;      // (A/B knob: 2 or 4)
+    if (forced == 2 || forced == 4) return forced;
+    return n_lanes > 1 ? 2 : 4;
+}
 static int pick_walk(int pipeline, int n_lanes) {
     (void)n_lanes;
     return pipeline == 5 ? PTK_WALK_THREADED : PTK_WALK_WIDE;
@@ -206,7 +211,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.ray_total = g.ray_total;
     l.ws.inline_bvh = inline_bvh_choice(g.pipeline);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
-    l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4;          // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
+    l.ws.wide_lpr = pick_lpr(g.n_lanes);            // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
     l.ws.segmented = (g.pipeline != 4);
     l.ws.capacity = g.capacity;
     l.last_iter = 0;
@@ -623,7 +628,7 @@ int ptk_debug_clear_image(void) {
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = g.n_lanes > 1 ? 2 : 4; l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = pick_lpr(g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     return 0;
