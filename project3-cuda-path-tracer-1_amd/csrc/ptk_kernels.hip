@@ -625,18 +625,22 @@ __device__ __forceinline__ int wide_leaf_visit(const uint4 l0, const uint4 l1, c
     return 1;
 }
 
+// threads per block of the wide walk: a block holds its LDS (and a new block needs all its wave slots at once) until its slowest ray is done
+#ifndef PTK_WIDE_BLOCK
+#define PTK_WIDE_BLOCK 256
+#endif
 template <bool STATS, int LPR>       // LPR lanes per ray (4: shortest chain; 2: fewer instructions per ray, see the header comment)
-__global__ void __launch_bounds__(PTK_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
+__global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
                                                               const int* __restrict__ srcidx) {
-    constexpr int RAYS = PTK_BLOCK / LPR, NCH = 8 / LPR;          // rays per block; children per lane
+    constexpr int RAYS = PTK_WIDE_BLOCK / LPR, NCH = 8 / LPR;     // rays per block; children per lane
     __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
     __shared__ unsigned s_stack[RAYS * PTK_WIDE_STRIDE];
     const int m = (int)*list_count;
     if (blockIdx.x * RAYS >= m) return;
     const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
     if (PTK_WIDE_TOP > 0) {
-        for (int k = threadIdx.x; k < n_top * 9; k += PTK_BLOCK) s_top[k] = S.wnodes[k];
+        for (int k = threadIdx.x; k < n_top * 9; k += PTK_WIDE_BLOCK) s_top[k] = S.wnodes[k];
         __syncthreads();
     }
     const int q = threadIdx.x & (LPR - 1);                       // lane within the ray's group
@@ -2144,9 +2148,9 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
-    if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
-    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
-    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
+    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
@@ -2271,8 +2275,8 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
         k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
         const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
-        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
-        else if (wide) k_traverse_wide<false, 4><<<4 * g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
         k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref);
