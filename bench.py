@@ -460,7 +460,9 @@ def main():
         if N == 1 and not a.lean and a.cpu_seconds > 0:
             cpu = cpu_baseline(scene_path, res, a.depth, mode, a.cpu_seconds)
         contracted = None
-        if N == 1 and not a.lean and ptk.FLAVOUR == "exact" and os.path.exists(os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "libptk_fma.so")):
+        # (never under a profiler: the child would inherit the preload, contend for the counters and land in the trace — ADVICE r3)
+        profiled = any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if N == 1 and not a.lean and not profiled and ptk.FLAVOUR == "exact" and os.path.exists(os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "libptk_fma.so")):
             # the opt-in "reference-device numerics" flavour (libptk_fma.so: -ffp-contract=fast like nvcc's -fmad=true), same workload, own
             # process (one flavour per process), reported beside the bit-exact headline, never instead of it
             import subprocess

@@ -96,6 +96,7 @@ void sync_all() { for (Lane& l : g.lanes) if (l.stream) (void)hipStreamSynchroni
 
 int context_free() {
     sync_all();
+    g_debug_slot_shift = 0;             // a test that died between set and reset must not shift the keys of later renders
     for (Lane& l : g.lanes) {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
@@ -358,8 +359,9 @@ void note_counts(Lane& L) {
     if (d_new > g.full_bounces || (d_new < g.full_bounces && cnt[d_new] <= kTailPaths / 2)) g.full_bounces = d_new;
     // camera rays that hit something / camera rays (fused pipeline, compact streams): below ~half, the camera launch stores the path state of
     // the hits only, after its trace phase (k_shade_trace, GenArgs::late_stores); hysteresis as above.  Results never depend on it.
+    // (only the hit-dense launches write hcounts[]: after a SPLIT launch h0 is a stale zero and would read as "open scene" — ADVICE r3)
     const long long n0 = L.h_counts[0], h0 = L.h_counts[g.traceDepth + 2];
-    if (n0 > 0 && use_trace_pipeline()) {
+    if (n0 > 0 && hit_dense_pipeline()) {
         if (!g.gen_late && 100 * h0 < 45 * n0) g.gen_late = 1;
         else if (g.gen_late && 100 * h0 > 55 * n0) g.gen_late = 0;
     }
@@ -600,14 +602,16 @@ int ptk_set_iteration_sharding(int n_shards, int shard) {
     g.n_shards = n_shards; g.shard = shard;
     return 0;
 }
-/* Bounces the render loop currently enqueues at full width (the rest of an iteration runs in the single-workgroup k_tail);
- * trace depth until live counts of earlier iterations have been seen.  Diagnostic. */
+/* 1 while the camera launch stores the path state of the hits only (open scene: fewer than ~half of the camera rays of earlier
+ * iterations hit something; note_counts).  Diagnostic. */
 int ptk_get_open_scene_hint(int* out) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!out) return PTK_E_BADARG;
     *out = g.gen_late;
     return 0;
 }
+/* Bounces the render loop currently enqueues at full width (the rest of an iteration runs in the single-workgroup k_tail);
+ * trace depth until live counts of earlier iterations have been seen.  Diagnostic. */
 int ptk_get_full_width_bounces(int* out) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!out) return PTK_E_BADARG;
@@ -631,6 +635,10 @@ int ptk_set_pipeline(int which) {
     for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = pick_lpr(g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
+    // the hints were learnt from the other pipeline's counters (hcounts[] is only written by the hit-dense launches): start again, like a
+    // sample-mode switch does
+    g.full_bounces = g.traceDepth; g.gen_late = 0;
+    for (Lane& l : g.lanes) { l.counts_pending = false; l.fresh_hint = 0; }
     return 0;
 }
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the

@@ -33,6 +33,7 @@ inline SceneView dev_view(const ::Scene& s) {
     d.trie = (const DevTriE*)t.dev_trie;
     d.wnodes = (const uint4*)t.dev_wnodes;       d.n_wnodes = t.wide_nodes;
     d.wleaves = (const uint4*)t.dev_wleaves;
+    d.occ = (const uint32_t*)t.dev_occ;
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
     d.tex = (const DevTex*)t.dev_textures;       d.texels = (const float*)t.dev_texture_data; d.env_tex = t.envMapID;

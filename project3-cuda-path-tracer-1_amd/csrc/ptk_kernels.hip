@@ -514,6 +514,114 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __rest
     if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *list_count = (unsigned)(prior + total);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_list_sorted: the same work list, ordered by PREDICTED TRAVERSAL COST inside chunks of PTK_LIST_BLOCK stream slots (round 4).
+//
+// A wave of k_traverse_wide serves 64 / LPR rays and runs for its slowest one; in path order the visit counts of neighbouring rays are
+// unrelated (bunny scene: mean 9.7 visits per listed ray, maximum 60-90) and ~35 % of the lane slots do work.  The ORDER of the list is
+// free: every result goes to its ray's own slot and no RNG key depends on it.  tools/diag/coherence_sim.py models the walk on the CPU
+// (per-ray visit counts over the host copy of the wide tree; cost of an order = sum over waves of the slowest ray): spatial keys (octant,
+// Morton cell of the entry point or of the chord's midpoint) buy 20 % sorted globally and under 10 % inside chunks; a cost PREDICTOR works
+// as well inside chunks of a few hundred rays as globally, because what it fixes is the mix of cheap and expensive rays in a wave, not
+// locality: children of the root node the ray hits x 3 + the traversal-cost table (PTK_OCC_*) sampled at 16 points of the ray's chord
+// through the root box — 0.71-0.74 of the unsorted cost (perfect knowledge of the visit counts: 0.36-0.42).  One thread per listed ray,
+// approximate reciprocals (nothing here decides a hit), ~350 instructions; LDS counting sort, heaviest first.
+// ------------------------------------------------------------------------------------------------------------------
+#define PTK_LIST_BLOCK 1024
+#define PTK_LIST_KEYS 128
+__global__ void __launch_bounds__(PTK_LIST_BLOCK) k_list_sorted(SceneView S, int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
+                                                                 const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count,
+                                                                 int whole_windows, PtkPaths paths, const int* __restrict__ srcidx, const float* __restrict__ t_n) {
+    constexpr int NT = PTK_LIST_BLOCK, NW = NT / 64;
+    __shared__ int s_idx[NT];
+    __shared__ int s_hist[PTK_LIST_KEYS];
+    __shared__ int s_red[NW], s_wsum[NW];
+    int n = d_n ? *d_n : n_arg;
+    if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (b * NT >= n) { if (n <= 0 && b == 0 && tid == 0) *list_count = 0u; return; }
+    const int i = b * NT + tid;
+    const int flag = (i < n) ? heavy_flag[i] : 0;
+    // listed rays of the earlier chunks: heavy_agg has one entry per 256 slots, and every entry below 4 b belongs to a block that ran
+    int prior = 0;
+    for (int k = tid; k < (NT / PTK_BLOCK) * b; k += NT) prior += heavy_agg[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o, 64);
+    const unsigned long long bal = __ballot(flag != 0);
+    if (lane == 0) { s_red[wid] = prior; s_wsum[wid] = __popcll(bal); }
+    if (tid < PTK_LIST_KEYS) s_hist[tid] = 0;
+    __syncthreads();
+    prior = 0;
+    int local = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { prior += s_red[w]; const int c = s_wsum[w]; local += (w < wid) ? c : 0; total += c; }
+    if (flag) s_idx[local] = i;
+    __syncthreads();
+    int key = 0, ray = 0, pos = 0;
+    if (tid < total) {                                           // one thread per listed ray of the chunk
+        ray = s_idx[tid];
+        const int src = srcidx ? srcidx[ray] : ray;
+        const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
+        const float t0 = t_n[4 * (size_t)ray];
+        const float tmax = t0 > 0.f ? t0 : FLT_MAX;
+        const float ix = __builtin_amdgcn_rcpf(d4.x), iy = __builtin_amdgcn_rcpf(d4.y), iz = __builtin_amdgcn_rcpf(d4.z);
+        const float* hdr = reinterpret_cast<const float*>(S.occ);
+        const float lx = hdr[0], ly = hdr[1], lz = hdr[2], sx = hdr[3], sy = hdr[4], sz = hdr[5];
+        // (a) children of the root node whose dequantised box the ray hits before tmax
+        const uint4* np = S.wnodes;
+        const uint4 q0 = np[0];
+        const float ex = __uint_as_float((q0.w & 0xffu) << 23), ey = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), ez = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+        const float bx = (__uint_as_float(q0.x) - o4.x) * ix, by = (__uint_as_float(q0.y) - o4.y) * iy, bz = (__uint_as_float(q0.z) - o4.z) * iz;
+        const float ax = ex * ix, ay = ey * iy, az = ez * iz;
+        const int nc = (int)(q0.w >> 24);
+        int hits = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 ch = np[1 + c];
+            const float x0 = __builtin_fmaf((float)(ch.x & 0xffu), ax, bx), x1 = __builtin_fmaf((float)(ch.x >> 24), ax, bx);
+            const float y0 = __builtin_fmaf((float)((ch.x >> 8) & 0xffu), ay, by), y1 = __builtin_fmaf((float)(ch.y & 0xffu), ay, by);
+            const float z0 = __builtin_fmaf((float)((ch.x >> 16) & 0xffu), az, bz), z1 = __builtin_fmaf((float)((ch.y >> 8) & 0xffu), az, bz);
+            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            hits += (c < nc && tn <= fminf(tf, tmax) && tf >= 0.f) ? 1 : 0;
+        }
+        // (b) the cost table along the ray's chord through the root box, clipped by the analytic hit
+        const float R = (float)PTK_OCC_RES;
+        const float hx = lx + R * __builtin_amdgcn_rcpf(sx), hy = ly + R * __builtin_amdgcn_rcpf(sy), hz = lz + R * __builtin_amdgcn_rcpf(sz);
+        const float u0 = (lx - o4.x) * ix, u1 = (hx - o4.x) * ix, v0 = (ly - o4.y) * iy, v1 = (hy - o4.y) * iy, w0 = (lz - o4.z) * iz, w1 = (hz - o4.z) * iz;
+        const float tn = fmaxf(fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fminf(w0, w1)), 0.f);
+        const float tf = fminf(fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)), tmax);
+        const unsigned char* cells = reinterpret_cast<const unsigned char*>(S.occ + 8);
+        const float dt = (tf - tn) * (1.0f / 16.0f);
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float t = __builtin_fmaf(dt, (float)k + 0.5f, tn);
+            const float px = (__builtin_fmaf(d4.x, t, o4.x) - lx) * sx, py = (__builtin_fmaf(d4.y, t, o4.y) - ly) * sy, pz = (__builtin_fmaf(d4.z, t, o4.z) - lz) * sz;
+            const int cx = (int)fminf(fmaxf(px, 0.f), R - 1.f), cy = (int)fminf(fmaxf(py, 0.f), R - 1.f), cz = (int)fminf(fmaxf(pz, 0.f), R - 1.f);      // (fmaxf drops a NaN)
+            sum += cells[(cz * PTK_OCC_RES + cy) * PTK_OCC_RES + cx];
+        }
+        key = min(PTK_LIST_KEYS - 1, 3 * hits + (sum >> 2));
+        pos = atomicAdd(&s_hist[key], 1);                        // (the order inside a bucket is free)
+    }
+    __syncthreads();
+    // start of every bucket, heaviest first: off[k] = rays with a larger key
+    if (tid < PTK_LIST_KEYS) {
+        const int v = s_hist[PTK_LIST_KEYS - 1 - tid];
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_red[wid] = incl;
+        s_idx[tid] = incl - v;                                   // (s_idx is dead: every listed ray holds its index in a register)
+    }
+    __syncthreads();
+    if (tid < total) {
+        const int r = PTK_LIST_KEYS - 1 - key;
+        list[prior + s_idx[r] + (r >= 64 ? s_red[0] : 0) + pos] = ray;
+    }
+    if (tid == 0 && b == (n - 1) / NT) *list_count = (unsigned)(prior + total);
+}
+
 // BVH traversal of the listed rays, one per lane (pathtrace.cu:236-279).  A triangle winner is parked as (u, v, t, tri) in
 // the ray's uv_ids slot with flag PTK_VALID_TRI; k_finalize expands it (and clears the list counter for the next bounce).
 template <bool STATS>
@@ -2127,6 +2235,15 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
     return launch_rc();
 }
 
+// the BVH work list: ordered by predicted traversal cost when the wide walk runs (k_list_sorted; PTK_LIST_SORT=0: path order, for A/B runs)
+static int launch_list(const SceneView& S, int n, const int* d_n, const int* hflag, const int* hagg, int* list, unsigned* queue, int whole_windows,
+                       bool wide, PtkPaths paths, const int* srcidx, const float* t_n, hipStream_t st) {
+    static const bool sorted = !(getenv("PTK_LIST_SORT") && atoi(getenv("PTK_LIST_SORT")) == 0);
+    if (sorted && wide && S.occ) k_list_sorted<<<(n + PTK_LIST_BLOCK - 1) / PTK_LIST_BLOCK, PTK_LIST_BLOCK, 0, st>>>(S, n, d_n, hflag, hagg, list, queue, whole_windows, paths, srcidx, t_n);
+    else k_list<<<grid_for(n), PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, whole_windows);
+    return launch_rc();
+}
+
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
@@ -2144,10 +2261,10 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg, G);
     else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg, G);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0);
-    rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
+    rc = launch_list(S, n, d_n, hflag, hagg, list, queue, 0, wide && !(stats && !wide_stats), cur, G.src, hits.t_n, st);
+    if (rc) { mark(1, false); return rc; }
     if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
@@ -2272,9 +2389,8 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     const int n_bound = gen ? n_pix * ws.spp : capacity;
     if (split) {
         mark(1, true);
-        k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1);
-        if ((rc = launch_rc())) { mark(1, false); return rc; }
         const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
+        if ((rc = launch_list(S, n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1, wide, nxt.paths, nullptr, nxt.hits.t_n, st))) { mark(1, false); return rc; }
         if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);

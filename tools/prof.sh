@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 bench.py "$@" > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 bench.py --lean 1 "$@" > $out/bench.json 2> $out/bench.err
 echo "rc=$?"
 ls -R $out | head -20
