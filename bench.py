@@ -456,6 +456,28 @@ def main():
             rr.close()
             ref_order = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(1e3 * tt / a.steps, 4), "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
                          "config": "iterations_in_flight 1, graph_replay false: the reference's accumulation order, bit-identical image"}
+        cpp_api = None
+        exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
+        if N == 1 and not a.lean and os.path.exists(exe):
+            # the drop-in C++ API (pathtraceInit / pathtrace / pathtraceFree of src/pathtrace.h:6-9, csrc/pathtrace.h) driven by the headless replay of
+            # main.cpp's loop, own process: wall time of the pathtrace() calls + ONE pathtraceResolve() (the host image for saveImage), SURVEY 8(d)'s
+            # definition of the metric.  `value`: the API's defaults (one iteration at a time = the reference's accumulation order); `overlapped`: the
+            # same calls with PTK-side knobs 3 in flight + graph replay; `eager`: a host image after EVERY call like pathtrace.cu:809-810
+            import subprocess
+            def headless(*flags):
+                c = subprocess.run([exe, scene_path, "--mode", a.mode, "--iters", str((a.warmup + a.steps) * IPS), "--warmup", str(a.warmup * IPS), "--no-save", *flags]
+                                   + (["--res", str(res[0]), str(res[1])] if res else []) + (["--depth", str(a.depth)] if a.depth >= 0 else []),
+                                   capture_output=True, text=True, timeout=600)
+                j = json.loads([l for l in c.stdout.splitlines() if l.startswith("cpp_api ")][-1][len("cpp_api "):])
+                return {"value": round(j["rays"] / j["seconds"] / 1e6, 3), "ms_per_iteration": round(1e3 * j["seconds"] / j["iterations"], 4)}
+            try:
+                cpp_api = dict(headless(), unit="Mrays/s",
+                               config="csrc/ptk_headless: pathtraceInit + %d x pathtrace(nullptr, 0, it) + pathtraceResolve(), API defaults (one iteration at a time)" % (a.steps * IPS),
+                               overlapped=headless("--in-flight", str(a.in_flight), "--graph", str(a.graph)),
+                               eager=headless("--eager"),
+                               eager_note="a resolve (7.7 MB D2H + host wait) after every call = what the reference's pathtrace() does (pathtrace.cu:809-810)")
+            except Exception as e:
+                cpp_api = {"error": str(e)[:200]}
         cpu = None
         if N == 1 and not a.lean and a.cpu_seconds > 0:
             cpu = cpu_baseline(scene_path, res, a.depth, mode, a.cpu_seconds)
@@ -501,7 +523,7 @@ def main():
             "device_ms_per_step": round(dev_ms / a.steps, 4), "ms_per_iteration": round(1e3 * elapsed / (a.steps * IPS), 4),
             "overlap_note": (f"{a.in_flight} iterations in flight on {a.in_flight} streams: ms_per_step is smaller than the sum of the "
                              "per-kernel times of one iteration (roofline.note) because iterations overlap") if a.in_flight > 1 else None,
-            "reference_order": ref_order,
+            "reference_order": ref_order, "cpp_api": cpp_api,
             "roofline": roofline, "cpu_baseline": cpu, "contracted": contracted, "flavour": ptk.FLAVOUR,
         }
         if multi is not None:

@@ -7,6 +7,10 @@
 // binary PPM (P6) and the raw float32 radiance sum (.f32).
 //
 // usage: ptk_headless SCENE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]
+//        [--warmup W] [--no-save] [--in-flight L] [--graph 0|1] [--eager]
+// Timing (bench.py `cpp_api`): --warmup W renders W untimed iterations first (then waits for the GPU); the timed region is the remaining
+// pathtrace() calls plus ONE pathtraceResolve() — what a viewer that saves the image at the end pays.  --eager resolves after every call
+// (the reference's pathtrace.cu:809-810 behaviour), --in-flight / --graph are the ptk_set_* knobs (defaults 1 / 0: the reference's order).
 #include "pathtrace.h"
 #include <chrono>
 #include <cmath>
@@ -90,7 +94,8 @@ static void saveImage(const Scene& scene, int iteration, const std::string& base
 
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("Usage: %s SCENEFILE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]\n", argv[0]); return 1; }
-    int iters = -1, rw = -1, rh = -1, depth = -1;
+    int iters = -1, rw = -1, rh = -1, depth = -1, warmup = 0, in_flight = 0, graph = -1;
+    bool save = true, eager = false;
     std::string out;
     for (int i = 2; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--mode") && i + 1 < argc) { const char* m = argv[++i]; sampleMode = !std::strcmp(m, "bsdf") ? BSDF : (!std::strcmp(m, "direct") ? DirectLi : MIS); }
@@ -99,6 +104,11 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else if (!std::strcmp(argv[i], "--light-fix")) ptk_set_light_fix(1);        // opt-in fixed cube lights (not reference behaviour)
+        else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--in-flight") && i + 1 < argc) in_flight = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--graph") && i + 1 < argc) graph = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--no-save")) save = false;
+        else if (!std::strcmp(argv[i], "--eager")) eager = true;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::printf("No HIP-capable devices were detected.\n"); return 2; }
@@ -116,16 +126,29 @@ int main(int argc, char** argv) {
     const int total = iters > 0 ? iters : (int)scene->state.iterations;
     if (out.empty()) out = scene->state.imageName.empty() ? std::string("render") : scene->state.imageName;
 
+    if (in_flight > 0 && ptk_set_iterations_in_flight(in_flight)) { std::printf("bad --in-flight\n"); return 5; }
+    if (graph >= 0) ptk_set_graph_replay(graph);
     int iteration = 0;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned long long rays0 = 0;
     while (true) {                                       // mainLoop -> runCuda
         if (iteration == 0) { pathtraceFree(); pathtraceInit(scene); }
-        if (iteration < total) { iteration++; pathtrace(nullptr, 0, iteration); }
+        if (iteration < total) {
+            iteration++; pathtrace(nullptr, 0, iteration);
+            if (eager) pathtraceResolve();               // what the reference does inside pathtrace() (pathtrace.cu:809-810)
+            if (iteration == warmup) { pathtraceResolve(); ptk_get_ray_total(&rays0); t0 = std::chrono::steady_clock::now(); }
+        }
         else break;
     }
+    pathtraceResolve();                                  // scene->state.image and TracedDepth as of the last call (the top of saveImage)
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("%d iterations in %.3f s (%.2f ms/iteration), TracedDepth %d\n", iteration, sec, 1e3 * sec / std::max(1, iteration), guiData->TracedDepth);
-    saveImage(*scene, iteration, out);
+    unsigned long long rays = 0;
+    ptk_get_ray_total(&rays);
+    const int timed = iteration - (warmup < iteration ? warmup : 0);
+    std::printf("%d iterations in %.3f s (%.2f ms/iteration), TracedDepth %d\n", iteration, sec, 1e3 * sec / std::max(1, timed), guiData->TracedDepth);
+    std::printf("cpp_api {\"iterations\": %d, \"warmup\": %d, \"seconds\": %.6f, \"rays\": %llu, \"eager\": %d, \"in_flight\": %d, \"graph\": %d}\n",
+                timed, warmup < iteration ? warmup : 0, sec, rays - rays0, eager ? 1 : 0, in_flight > 0 ? in_flight : 1, graph > 0 ? 1 : 0);
+    if (save) saveImage(*scene, iteration, out);
     pathtraceFree();
     Resource::clear();
     scene->clear();

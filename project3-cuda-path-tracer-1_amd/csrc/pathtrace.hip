@@ -71,6 +71,9 @@ struct RenderContext {
     int hint_mode = -1;                 // sample mode the full_bounces hint was learnt under
     int n_shards = 1, shard = 0;        // iteration sharding (ptk_set_iteration_sharding): call `step` renders iteration (step-1)*n_shards + shard + 1
     bool live = false;
+    // C++ API (pathtrace.h): scene->state.image is made current on demand (pathtraceResolve), not after every call
+    void* host_image_reg = nullptr;     // state.image's storage, pinned in place (hipHostRegister) so that the D2H copy is one asynchronous DMA
+    bool eager_image = false;           // PTK_EAGER_IMAGE=1: resolve after every pathtrace() call, as pathtrace.cu:809-810 does
 } g;
 
 int g_mode_override = -1;               // ptk_set_sample_mode; -1 = follow the `sampleMode` global
@@ -113,6 +116,7 @@ int context_free() {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     g.lanes.clear();
+    if (g.host_image_reg) { (void)hipHostUnregister(g.host_image_reg); g.host_image_reg = nullptr; }
     if (g.image != g.planes) dfree(g.image);
     g.image = nullptr;
     dfree(g.planes); dfree(g.ray_total);
@@ -350,6 +354,8 @@ constexpr int kTailPaths = 1024;                 // a bounce with at most this m
 void note_counts(Lane& L) {
     if (!L.counts_pending || hipEventQuery(L.counts_ev) != hipSuccess) return;
     L.counts_pending = false;
+    if (g.gui) { int d = 0; while (d < g.traceDepth && L.h_counts[d] > 0) ++d; g.gui->TracedDepth = d; }      // pathtrace.cu:793-796, one read-back late
+    if (!sparse_tail()) return;
     // what k_tail looks at in its first bounce: the live paths — or, after a hit-dense launch, only the paths that hit something (mis_test.txt:
     // 1 088 live but 43 hits at bounce 2: the tail takes over one 20-us launch earlier)
     const int* cnt = hit_dense_pipeline() ? L.h_counts + g.traceDepth + 2 : L.h_counts;
@@ -367,7 +373,7 @@ void note_counts(Lane& L) {
     }
 }
 int request_counts(Lane& L) {
-    if (!sparse_tail() || L.counts_pending) return 0;
+    if ((!sparse_tail() && !g.gui) || L.counts_pending) return 0;      // (the viewer's TracedDepth rides on the same read-back)
     // the counts of a static scene barely move: look every iteration at first, then at every 16th (each look is a ~5-us copy kernel on the stream)
     if (++L.fresh_hint > 8 && L.fresh_hint % 16 != 0) return 0;
     hipError_t e = hipMemcpyAsync(L.h_counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
@@ -714,20 +720,50 @@ int ptk_timer_stop(float* ms) {
 // ---------------------------------------------------------------- C++ API (pathtrace.h)
 void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
-void pathtraceInit(Scene* scene) { PTK_CHECK("pathtraceInit", context_init(scene)); }
+// Knobs of the C++ API, read at pathtraceInit (the four reference signatures have no room for them): PTK_IN_FLIGHT=<L> iterations in flight,
+// PTK_GRAPH=1 hipGraph replay (both as ptk_set_*; defaults 1 / 0 = the reference's accumulation order), PTK_EAGER_IMAGE=1 = refresh
+// scene->state.image after EVERY call like pathtrace.cu:809-810 (a 7.7 MB D2H and a host wait per 0.3 ms iteration at 800 x 800).
+void pathtraceInit(Scene* scene) {
+    if (!g.live) {
+        if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.n_lanes = l; }
+        if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;
+    }
+    PTK_CHECK("pathtraceInit", context_init(scene));
+    g.eager_image = getenv("PTK_EAGER_IMAGE") && atoi(getenv("PTK_EAGER_IMAGE")) != 0;
+    // the host image lives where the reference keeps it; pinned in place, so that pathtraceResolve's copy is one asynchronous DMA.  The
+    // reference never resizes it after pathtraceInit (main.cpp:146-170 only reads it); if pinning fails the copy is a plain pageable one.
+    std::vector<ptk::vec3>& img = scene->state.image;
+    img.assign((size_t)g.P, ptk::vec3());
+    if (hipHostRegister(img.data(), sizeof(ptk::vec3) * img.size(), hipHostRegisterDefault) == hipSuccess) g.host_image_reg = img.data();
+    else (void)hipGetLastError();
+}
 
 void pathtraceFree() { PTK_CHECK("pathtraceFree", context_free()); }
 
-void pathtrace(uchar4* pbo, int frame, int iteration) {
-    PTK_CHECK("pathtrace", ptk_pathtrace(reinterpret_cast<unsigned char*>(pbo), frame, iteration));
-    // pathtrace.cu:809-810: the host copy of the running sum is refreshed after every call
+// Not a reference function.  scene->state.image (the running radiance SUM, pathtrace.cu:809-810) and guiData->TracedDepth
+// (pathtrace.cu:793-796) as of the last pathtrace() call; waits for the GPU.  SURVEY 8(b) "Outputs": the per-iteration D2H may be lazy as
+// long as state.image is current when saveImage() runs — the maintainer calls this at the top of saveImage().
+void pathtraceResolve() {
+    if (!g.live) return;
     std::vector<ptk::vec3>& img = g.scene->state.image;
-    if ((int)img.size() != g.P) img.assign((size_t)g.P, ptk::vec3());
-    PTK_CHECK("pathtrace", ptk_get_image(reinterpret_cast<float*>(img.data())));
-    if (g.gui) {                                       // pathtrace.cu:793-796
+    if ((int)img.size() != g.P || (g.host_image_reg && g.host_image_reg != (void*)img.data())) {      // the caller replaced the vector: pin the new one
+        if (g.host_image_reg) { (void)hipHostUnregister(g.host_image_reg); g.host_image_reg = nullptr; }
+        if ((int)img.size() != g.P) img.assign((size_t)g.P, ptk::vec3());
+        if (hipHostRegister(img.data(), sizeof(ptk::vec3) * img.size(), hipHostRegisterDefault) == hipSuccess) g.host_image_reg = img.data();
+        else (void)hipGetLastError();
+    }
+    PTK_CHECK("pathtraceResolve", ptk_get_image(reinterpret_cast<float*>(img.data())));
+    if (g.gui) {
         std::vector<int> counts((size_t)g.traceDepth + 1);
         int depth = 0;
-        PTK_CHECK("pathtrace", ptk_get_live_counts(counts.data(), &depth));
+        PTK_CHECK("pathtraceResolve", ptk_get_live_counts(counts.data(), &depth));
         g.gui->TracedDepth = depth;
     }
+}
+
+void pathtrace(uchar4* pbo, int frame, int iteration) {
+    // enqueue only: no host wait, no D2H.  TracedDepth follows from the asynchronous counts read-back (note_counts), a call or more late;
+    // pathtraceResolve() makes both exact.
+    PTK_CHECK("pathtrace", ptk_pathtrace(reinterpret_cast<unsigned char*>(pbo), frame, iteration));
+    if (g.eager_image) pathtraceResolve();
 }

@@ -26,11 +26,11 @@ def test_every_entry_point_cites_the_reference():
 
 
 def test_cpp_api_symbols_exported(ptk):
-    """pathtrace.h's four C++ functions (mangled) are in the library, plus the weak `sampleMode` global."""
+    """pathtrace.h's four C++ functions (mangled) are in the library, plus pathtraceResolve (the lazy host image) and the weak `sampleMode` global."""
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", ptk.LIB_PATH], capture_output=True, text=True).stdout
     for sym in ("_Z13pathtraceInitP5Scene", "_Z13pathtraceFreev", "_Z9pathtraceP15HIP_vector_typeIhLj4EEii",
-                "_Z17InitDataContainerP16GuiDataContainer", "sampleMode"):
+                "_Z17InitDataContainerP16GuiDataContainer", "_Z16pathtraceResolvev", "sampleMode"):
         assert sym in out, sym
 
 

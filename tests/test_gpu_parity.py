@@ -389,6 +389,30 @@ def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
     assert png.shape == (48, 64, 3) and np.array_equal(png, pix)
 
 
+@pytest.mark.parametrize("flags,lanes", [((), 1), (("--eager",), 1), (("--in-flight", "3", "--graph", "1"), 3)])
+def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, flags, lanes):
+    """The C++ pathtrace() only enqueues (no D2H, no host wait, SURVEY 8b "Outputs"); pathtraceResolve() makes scene->state.image and
+    TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle, bit for bit — in the reference's order, with a
+    resolve after every call (--eager = pathtrace.cu:809-810) and with three iterations in flight + graph replay (ordered plane sum)."""
+    import subprocess
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
+    base = str(tmp_path / "lazy")
+    W, H, D = 200, 160, 5
+    cmd = [exe, os.path.join(SC, "cornell.txt"), "--mode", "mis", "--iters", "6", "--res", str(W), str(H), "--depth", str(D), "--out", base, *flags]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"TracedDepth {D}" in r.stdout and "cpp_api {" in r.stdout
+    img = np.fromfile(base + ".6samp.f32", np.float32).reshape(-1, 3)
+    o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
+    planes = np.zeros((lanes, o.P, 3), np.float32)
+    for it in range(1, 7):
+        o.pathtrace(orc.MODE_MIS, it, planes[(it - 1) % lanes])
+    ref = planes[0].copy()
+    for l in range(1, lanes):
+        ref += planes[l]
+    assert np.array_equal(img, ref)
+
+
 def test_compact_edges(ptk, torch_cuda):
     """Stable compaction: empty, single, block-boundary and ragged sizes, all-dead / all-alive / random flags."""
     torch = torch_cuda
