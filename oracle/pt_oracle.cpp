@@ -349,6 +349,10 @@ static inline float sample1D(Rng& r) {
 // g_dbg_slot_shift is an analysis knob of the gallery test only: it offsets the compacted slot in the shading RNG key
 // (the reference's GPU build flips a few sphere-silhouette hits per iteration, which shifts every later slot).
 static int g_dbg_slot_shift = 0;
+static int g_dbg_slot_shift_deep = 0, g_dbg_deep_on = 0;      // diagnostic (tools/diag/mis20_residue.py): a separate offset for depth >= 1
+static int g_dbg_min_depth = 0;                                // diagnostic: only contributions made at depth >= this reach the image (MIS)
+static inline int dbg_shift(int depth) { return (g_dbg_deep_on && depth >= 1) ? g_dbg_slot_shift_deep : g_dbg_slot_shift; }
+static int g_dbg_mis_terms = 3;      // diagnostic: MisPTkernel terms that reach the image (orc_set_debug_mis_terms)
 // tile partition (not a reference feature): rank `part` keys its shading RNG with slot + part * W * H * spp so that two ranks never
 // share a random stream; 0 without a partition = the reference's key (pathtrace.cu:363,458,532)
 static int g_slot_bias = 0;
@@ -1016,7 +1020,7 @@ static int shade_bsdf(const OrcScene& S, int iter, int idx, int depth, const Ise
     int valid = 0;
     const Material& m = S.materials[is.materialId];
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
-    Rng rng = make_rng(iter, idx + g_dbg_slot_shift + g_slot_bias, depth);
+    Rng rng = make_rng(iter, idx + dbg_shift(depth) + g_slot_bias, depth);
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     if (srec.pdf == 0) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
@@ -1038,7 +1042,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
     const Material& m = S.materials[is.materialId];
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
     bool isDelta = (m.type == MAT_DIELECTRIC);
-    Rng rng = make_rng(iter, idx + g_dbg_slot_shift + g_slot_bias, depth);
+    Rng rng = make_rng(iter, idx + dbg_shift(depth) + g_slot_bias, depth);
     ScatterRec srec;
     scatterSample(m, is, ps.d, srec, rng);
     v3 viewPos = is.p, viewNor = is.n;
@@ -1052,7 +1056,8 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
         }
         ps.color = ps.color * ((srec.bsdf / srec.pdf) * weight);
         ps.remainingBounces = 0;
-        v3 c = processNAN(ps.color); px[0] += c.x; px[1] += c.y; px[2] += c.z;
+        v3 c = processNAN(ps.color);
+        if ((g_dbg_mis_terms & 1) && depth >= g_dbg_min_depth) { px[0] += c.x; px[1] += c.y; px[2] += c.z; }
         return 0;
     }
     if (!isDelta) {
@@ -1064,7 +1069,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
         v3 Libsdf = matBSDF(m, is, ps.d, Liwi);
         float weight = powerHeuristic(lightPdf, bsdfPdf);
         v3 c = processNAN(weight * ps.color * Li.emit * Libsdf * gmax(dot(Liwi, is.n), 0.f) / lightPdf);
-        px[0] += c.x; px[1] += c.y; px[2] += c.z;
+        if ((g_dbg_mis_terms & 2) && depth >= g_dbg_min_depth) { px[0] += c.x; px[1] += c.y; px[2] += c.z; }
     }
     shade_continue(ps, is, srec, m.type, valid);
     ps.prevPdf = isDelta ? -1.f : srec.pdf;
@@ -1074,7 +1079,7 @@ static int shade_mis(const OrcScene& S, int iter, int idx, int depth, const Isec
 
 // pathtrace.cu:348-403 DirectLiPTkernel, one path (always rayValid = 0)
 static int shade_direct(const OrcScene& S, int iter, int idx, int depth, const Isect& is, PathSegment& ps, float* img) {
-    Rng rng = make_rng(iter, idx + g_dbg_slot_shift + g_slot_bias, depth);
+    Rng rng = make_rng(iter, idx + dbg_shift(depth) + g_slot_bias, depth);
     const Material& m = S.materials[is.materialId];
     float* px = radiance_px(img, ps.pixelIndex);
     if (is.t <= 0.f) { ps.color = ps.color * 0.f; ps.remainingBounces = 0; return 0; }
@@ -1472,6 +1477,13 @@ extern "C" {
 
 void orc_set_trig_mode(int m) { g_trig_mode = m; }
 void orc_set_debug_slot_shift(int k) { g_dbg_slot_shift = k; }
+// diagnostic (tools/diag/mis20_residue.py): which of MisPTkernel's two radiance terms reach the image — 1 the BSDF-sampled light hits
+// (pathtrace.cu:545-556), 2 the next-event samples (:558-571), 3 both (default); the paths themselves are unchanged
+void orc_set_debug_mis_terms(int mask) { g_dbg_mis_terms = mask; }
+// diagnostics of the same script: a compacted-slot offset of its own for depth >= 1 (on = 0: the common offset applies at every depth), and
+// a lower bound on the depth whose MIS contributions reach the image
+void orc_set_debug_slot_shift_deep(int on, int k) { g_dbg_deep_on = on; g_dbg_slot_shift_deep = k; }
+void orc_set_debug_min_depth(int d) { g_dbg_min_depth = d; }
 void orc_set_sample2d_order(int xfirst) { g_s2d_xfirst = xfirst ? 1 : 0; }
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 void orc_set_light_fix(int on) { g_light_fix = on ? 1 : 0; }

@@ -200,7 +200,7 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.ws.valid_b, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.ws.counts, (size_t)g.traceDepth + 2))) return rc;
-    if ((rc = dalloc(&l.ws.queue, 1))) return rc;
+    if ((rc = dalloc(&l.ws.queue, 4))) return rc;          // {listed, front, back, -} (ptk_kernels.hip: list_pos)
     if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
     if ((rc = dalloc(&l.ws.srcidx, (size_t)g.capacity))) return rc;
@@ -210,7 +210,7 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
     if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
     l.ws.seg_done = fold_segments(g.pipeline, g.n_lanes) ? l.seg_done_mem : nullptr;
-    if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(l.ws.queue, 0, 4 * sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.hcounts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;

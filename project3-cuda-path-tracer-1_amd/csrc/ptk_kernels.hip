@@ -504,14 +504,14 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __rest
     int n = d_n ? *d_n : n_arg;
     if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;      // fused pipeline: flags live at physical slots, every slot of a window is written
     const int b = blockIdx.x;
-    if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0) *list_count = 0u; return; }
+    if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0) { list_count[0] = 0u; list_count[1] = 0u; list_count[2] = 0u; } return; }
     const int i = b * PTK_BLOCK + threadIdx.x;
     const int flag = (i < n) ? heavy_flag[i] : 0;
     int total;
     const int local = block_excl_prefix(flag, total);
     const int prior = prior_blocks(heavy_agg, b);
     if (flag) list[prior + local] = i;
-    if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *list_count = (unsigned)(prior + total);
+    if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) { list_count[0] = (unsigned)(prior + total); list_count[1] = (unsigned)(prior + total); list_count[2] = 0u; }      // (all "front": list_pos(j) = j)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -527,53 +527,58 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __rest
 // through the root box — 0.71-0.74 of the unsorted cost (perfect knowledge of the visit counts: 0.36-0.42).  One thread per listed ray,
 // approximate reciprocals (nothing here decides a hit), ~350 instructions; LDS counting sort, heaviest first.
 // ------------------------------------------------------------------------------------------------------------------
-#define PTK_LIST_BLOCK 1024
+#define PTK_LIST_SLOTS 1024       // stream slots per block of k_list_sorted (the chunk inside which rays are ordered)
 #define PTK_LIST_KEYS 128
-__global__ void __launch_bounds__(PTK_LIST_BLOCK) k_list_sorted(SceneView S, int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
-                                                                 const int* __restrict__ heavy_agg, int* __restrict__ list, unsigned* __restrict__ list_count,
-                                                                 int whole_windows, PtkPaths paths, const int* __restrict__ srcidx, const float* __restrict__ t_n) {
-    constexpr int NT = PTK_LIST_BLOCK, NW = NT / 64;
-    __shared__ int s_idx[NT];
-    __shared__ int s_hist[PTK_LIST_KEYS];
-    __shared__ int s_red[NW], s_wsum[NW];
+// list_count[0..2] = {rays listed by the plain k_list, FRONT rays, BACK rays}.  k_list_sorted places the rays whose key reaches `front_key` from
+// list[0] upwards and the others from list[list_cap - 1] downwards (one atomic per block and class; the order of the chunks is free), so that
+// the rays with the long dependent chains are all in flight from the first moment — the walk's duration is its slowest ray's chain, not its
+// instruction count.  k_finalize / k_finalize2 clear the counters.  Listed ray j of the walk sits at list[list_pos(j)].
+__device__ __forceinline__ int list_pos(int j, int n_front, int n_back, int list_cap) { return j < n_front ? j : list_cap - n_back + (j - n_front); }
+__global__ void __launch_bounds__(PTK_BLOCK) k_list_sorted(SceneView S, int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
+                                                            int* __restrict__ list, unsigned* __restrict__ list_count, int list_cap, int front_key,
+                                                            int whole_windows, PtkPaths paths, const int* __restrict__ srcidx, const float* __restrict__ t_n) {
+    constexpr int NT = PTK_BLOCK, PER = PTK_LIST_SLOTS / NT;
+    __shared__ int s_idx[PTK_LIST_SLOTS];
+    __shared__ int s_kp[PTK_LIST_SLOTS];
+    __shared__ int s_hist[PTK_LIST_KEYS], s_off[PTK_LIST_KEYS];
+    __shared__ int s_cnt, s_half, s_base[3];
     int n = d_n ? *d_n : n_arg;
     if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (b * NT >= n) { if (n <= 0 && b == 0 && tid == 0) *list_count = 0u; return; }
-    const int i = b * NT + tid;
-    const int flag = (i < n) ? heavy_flag[i] : 0;
-    // listed rays of the earlier chunks: heavy_agg has one entry per 256 slots, and every entry below 4 b belongs to a block that ran
-    int prior = 0;
-    for (int k = tid; k < (NT / PTK_BLOCK) * b; k += NT) prior += heavy_agg[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o, 64);
-    const unsigned long long bal = __ballot(flag != 0);
-    if (lane == 0) { s_red[wid] = prior; s_wsum[wid] = __popcll(bal); }
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (b * PTK_LIST_SLOTS >= n) return;
+    if (tid == 0) s_cnt = 0;
     if (tid < PTK_LIST_KEYS) s_hist[tid] = 0;
     __syncthreads();
-    prior = 0;
-    int local = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+    // the chunk's listed rays -> s_idx (one LDS atomic per wave and pass; their order is free)
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { prior += s_red[w]; const int c = s_wsum[w]; local += (w < wid) ? c : 0; total += c; }
-    if (flag) s_idx[local] = i;
+    for (int k = 0; k < PER; ++k) {
+        const int i = b * PTK_LIST_SLOTS + k * NT + tid;
+        const int flag = (i < n) ? heavy_flag[i] : 0;
+        const unsigned long long bal = __ballot(flag != 0);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_cnt, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (flag) s_idx[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    }
     __syncthreads();
-    int key = 0, ray = 0, pos = 0;
-    if (tid < total) {                                           // one thread per listed ray of the chunk
-        ray = s_idx[tid];
+    const int total = s_cnt;
+    const float* hdr = reinterpret_cast<const float*>(S.occ);
+    const float lx = hdr[0], ly = hdr[1], lz = hdr[2], sx = hdr[3], sy = hdr[4], sz = hdr[5];
+    const unsigned char* cells = reinterpret_cast<const unsigned char*>(S.occ + 8);
+    const uint4* np = S.wnodes;
+    const uint4 q0 = np[0];
+    const int nc = (int)(q0.w >> 24);
+    for (int j = tid; j < total; j += NT) {                      // one thread per listed ray: predicted traversal cost
+        const int ray = s_idx[j];
         const int src = srcidx ? srcidx[ray] : ray;
         const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         const float t0 = t_n[4 * (size_t)ray];
         const float tmax = t0 > 0.f ? t0 : FLT_MAX;
         const float ix = __builtin_amdgcn_rcpf(d4.x), iy = __builtin_amdgcn_rcpf(d4.y), iz = __builtin_amdgcn_rcpf(d4.z);
-        const float* hdr = reinterpret_cast<const float*>(S.occ);
-        const float lx = hdr[0], ly = hdr[1], lz = hdr[2], sx = hdr[3], sy = hdr[4], sz = hdr[5];
         // (a) children of the root node whose dequantised box the ray hits before tmax
-        const uint4* np = S.wnodes;
-        const uint4 q0 = np[0];
         const float ex = __uint_as_float((q0.w & 0xffu) << 23), ey = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), ez = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
         const float bx = (__uint_as_float(q0.x) - o4.x) * ix, by = (__uint_as_float(q0.y) - o4.y) * iy, bz = (__uint_as_float(q0.z) - o4.z) * iz;
         const float ax = ex * ix, ay = ey * iy, az = ez * iz;
-        const int nc = (int)(q0.w >> 24);
         int hits = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -591,7 +596,6 @@ __global__ void __launch_bounds__(PTK_LIST_BLOCK) k_list_sorted(SceneView S, int
         const float u0 = (lx - o4.x) * ix, u1 = (hx - o4.x) * ix, v0 = (ly - o4.y) * iy, v1 = (hy - o4.y) * iy, w0 = (lz - o4.z) * iz, w1 = (hz - o4.z) * iz;
         const float tn = fmaxf(fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fminf(w0, w1)), 0.f);
         const float tf = fminf(fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)), tmax);
-        const unsigned char* cells = reinterpret_cast<const unsigned char*>(S.occ + 8);
         const float dt = (tf - tn) * (1.0f / 16.0f);
         int sum = 0;
 #pragma unroll
@@ -601,25 +605,37 @@ __global__ void __launch_bounds__(PTK_LIST_BLOCK) k_list_sorted(SceneView S, int
             const int cx = (int)fminf(fmaxf(px, 0.f), R - 1.f), cy = (int)fminf(fmaxf(py, 0.f), R - 1.f), cz = (int)fminf(fmaxf(pz, 0.f), R - 1.f);      // (fmaxf drops a NaN)
             sum += cells[(cz * PTK_OCC_RES + cy) * PTK_OCC_RES + cx];
         }
-        key = min(PTK_LIST_KEYS - 1, 3 * hits + (sum >> 2));
-        pos = atomicAdd(&s_hist[key], 1);                        // (the order inside a bucket is free)
+        const int key = min(PTK_LIST_KEYS - 1, 3 * hits + (sum >> 2));
+        s_kp[j] = (key << 16) | atomicAdd(&s_hist[key], 1);     // (the order inside a bucket is free)
     }
     __syncthreads();
-    // start of every bucket, heaviest first: off[k] = rays with a larger key
+    // start of every bucket, heaviest first: s_off[r] = rays with a key above 127 - r; the block's FRONT rays = those with key >= front_key
     if (tid < PTK_LIST_KEYS) {
         const int v = s_hist[PTK_LIST_KEYS - 1 - tid];
         int incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) s_red[wid] = incl;
-        s_idx[tid] = incl - v;                                   // (s_idx is dead: every listed ray holds its index in a register)
+        if (tid == 63) s_half = incl;
+        s_off[tid] = incl - v;
     }
     __syncthreads();
-    if (tid < total) {
-        const int r = PTK_LIST_KEYS - 1 - key;
-        list[prior + s_idx[r] + (r >= 64 ? s_red[0] : 0) + pos] = ray;
+    if (tid == 0) {
+        const int fk = min(max(front_key, 0), PTK_LIST_KEYS);    // front = keys fk .. 127 = reversed buckets 0 .. 127 - fk
+        const int rf = PTK_LIST_KEYS - fk;                       // number of reversed buckets in front
+        const int nfb = rf <= 0 ? 0 : (rf >= PTK_LIST_KEYS ? total : s_off[rf] + (rf >= 64 ? s_half : 0));
+        s_base[0] = nfb;
+        s_base[1] = nfb ? (int)atomicAdd(&list_count[1], (unsigned)nfb) : 0;
+        s_base[2] = (total - nfb) ? (int)atomicAdd(&list_count[2], (unsigned)(total - nfb)) : 0;
     }
-    if (tid == 0 && b == (n - 1) / NT) *list_count = (unsigned)(prior + total);
+    __syncthreads();
+    const int nfb = s_base[0], front_base = s_base[1], back_base = s_base[2];
+    for (int j = tid; j < total; j += NT) {
+        const int kp = s_kp[j], key = kp >> 16, r = PTK_LIST_KEYS - 1 - key;
+        const int rank = s_off[r] + (r >= 64 ? s_half : 0) + (kp & 0xffff);
+        const int ray = s_idx[j];
+        if (rank < nfb) list[front_base + rank] = ray;
+        else list[list_cap - 1 - (back_base + (rank - nfb))] = ray;
+    }
 }
 
 // BVH traversal of the listed rays, one per lane (pathtrace.cu:236-279).  A triangle winner is parked as (u, v, t, tri) in
@@ -628,7 +644,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                          PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
                                                          const int* __restrict__ srcidx) {
-    const int m = (int)*list_count;
+    const int m = (int)(list_count[1] + list_count[2]);       // (always in path order here: k_list)
     const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (blockIdx.x * PTK_BLOCK >= m) return;
     unsigned nv = 0, nt = 0;
@@ -740,11 +756,11 @@ __device__ __forceinline__ int wide_leaf_visit(const uint4 l0, const uint4 l1, c
 template <bool STATS, int LPR>       // LPR lanes per ray (4: shortest chain; 2: fewer instructions per ray, see the header comment)
 __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
-                                                              const int* __restrict__ srcidx) {
+                                                              const int* __restrict__ srcidx, int list_cap, int stats_mode = 0) {
     constexpr int RAYS = PTK_WIDE_BLOCK / LPR, NCH = 8 / LPR;     // rays per block; children per lane
     __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
     __shared__ unsigned s_stack[RAYS * PTK_WIDE_STRIDE];
-    const int m = (int)*list_count;
+    const int n_front = (int)list_count[1], n_back = (int)list_count[2], m = n_front + n_back;
     if (blockIdx.x * RAYS >= m) return;
     const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
     if (PTK_WIDE_TOP > 0) {
@@ -756,7 +772,7 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
     const int j = blockIdx.x * RAYS + threadIdx.x / LPR;
     unsigned nv = 0, nt = 0;
     if (j < m) {
-        const int ray = list[j];
+        const int ray = list[list_pos(j, n_front, n_back, list_cap)];
         const int src = srcidx ? srcidx[ray] : ray;
         const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         const float t0 = hits.t_n[4 * (size_t)ray];
@@ -851,6 +867,19 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
     }
     if (STATS && stats) {
         unsigned long long a = nv, c = nt;
+        if (stats_mode == 2) {
+            // PTK_WIDE_STATS=2 (lane-busy diagnostic): stats[0] += the visits of the wave's slowest ray (what the wave runs for), stats[1] += the
+            // visits of all its rays; busy lane share = stats[1] / (stats[0] x rays per wave)
+            unsigned trips = nv + nt;                            // (counted by lane 0 of every group)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(trips, o, 64); trips = t > trips ? t : trips; }
+            c = a + c; a = 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+            a = trips;
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
+            return;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], c); }
@@ -858,9 +887,10 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
 }
 
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits,
-                                                         int* __restrict__ valid, int* __restrict__ agg) {
+                                                         int* __restrict__ valid, int* __restrict__ agg, unsigned* __restrict__ list_count) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x < 3) list_count[threadIdx.x] = 0u;       // the walk is over: clear the work-list counters for the next bounce
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     int flag = 0;
@@ -888,9 +918,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
 // PTK_VALID_TRI; writes the hit rank of every slot (hr: >= 0 rank among the hits of its window, -1 miss, -2 empty) and the window's
 // hit count, from which its last block builds hit_pref (a triangle hit changes the ranks the shading keys are made of).
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits, const int* __restrict__ valid,
-                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref) {
+                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref,
+                                                          unsigned* __restrict__ list_count) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x < 3) list_count[threadIdx.x] = 0u;       // the walk is over: clear the work-list counters for the next bounce
     if (b * PTK_BLOCK >= n) {
         if (n <= 0 && b == 0 && threadIdx.x < 8) hit_pref[threadIdx.x] = 0;
         return;
@@ -1543,18 +1575,26 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     const int step = iter_ptr ? *iter_ptr : iter_arg;
     const int n = GEN ? gen.n_pix * spp : (d_n ? *d_n : n_arg);      // paths of the bounce being shaded (GEN: rays to generate)
     const Film img = {img_base, plane_stride};
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (b * NT >= n) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if ((int)blockIdx.x * NT >= n) {
         // no live path at all: nobody runs the tail, block 0 does the (empty) bookkeeping of the bounce
-        if (n <= 0 && b == 0) {
+        if (n <= 0 && blockIdx.x == 0) {
             if (tail.hit_pref && tid < 8) tail.hit_pref[tid] = 0;
             if (tail.hcount_out && tid == 0) *tail.hcount_out = 0;
             segments_block<NT, false>(0, io.agg_s, tail.pref, tail.first, tail.count_out, tail.iter_advance, tail.iter_stride);
         }
         return;
     }
-    if (tid < NT / 64) { s_alive[tid] = 0ull; if (DEFER_NEE) { s_occ[tid] = 0ull; s_anyreq = 0; } }      // (published by the barrier in stage_geoms / stage_materials)
     const GeomStage gs = stage_geoms(S);                           // the trace phase always needs the primitives; MIS / DIRECT shading too
+#ifdef PTK_PERSISTENT
+    // A/B build (tools/diag/build_variant.sh persist -DPTK_PERSISTENT): an occupancy-sized grid whose blocks loop over the windows b, b + G, ...;
+    // the primitives are staged once per block (the materials share LDS with the pair list and are staged per window)
+    for (int b = blockIdx.x; b * NT < n; b += gridDim.x) {
+    __syncthreads();                                               // the previous window's LDS reads are over
+#else
+    { const int b = blockIdx.x;
+#endif
+    if (tid < NT / 64) { s_alive[tid] = 0ull; if (DEFER_NEE) { s_occ[tid] = 0ull; s_anyreq = 0; } }      // (published by the barrier in stage_materials)
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int alive = 0, my_rank = -1;           // this thread's shaded path survives, at rank my_rank of the window
@@ -1844,6 +1884,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         io.hr_nxt[b * NT + tid] = -2;
     }
     segments_tail2<NT>(tail, n, b, total, hits, io.agg_s, SPLIT ? nullptr : io.agg_h);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2236,10 +2277,11 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 }
 
 // the BVH work list: ordered by predicted traversal cost when the wide walk runs (k_list_sorted; PTK_LIST_SORT=0: path order, for A/B runs)
-static int launch_list(const SceneView& S, int n, const int* d_n, const int* hflag, const int* hagg, int* list, unsigned* queue, int whole_windows,
+static int launch_list(const SceneView& S, int n, const int* d_n, const int* hflag, const int* hagg, int* list, unsigned* queue, int list_cap, int whole_windows,
                        bool wide, PtkPaths paths, const int* srcidx, const float* t_n, hipStream_t st) {
     static const bool sorted = !(getenv("PTK_LIST_SORT") && atoi(getenv("PTK_LIST_SORT")) == 0);
-    if (sorted && wide && S.occ) k_list_sorted<<<(n + PTK_LIST_BLOCK - 1) / PTK_LIST_BLOCK, PTK_LIST_BLOCK, 0, st>>>(S, n, d_n, hflag, hagg, list, queue, whole_windows, paths, srcidx, t_n);
+    static const int front_key = getenv("PTK_LIST_FRONT_KEY") ? atoi(getenv("PTK_LIST_FRONT_KEY")) : 20;      // (A/B knob; 0: one class, only the order inside the chunks)
+    if (sorted && wide && S.occ) k_list_sorted<<<(n + PTK_LIST_SLOTS - 1) / PTK_LIST_SLOTS, PTK_BLOCK, 0, st>>>(S, n, d_n, hflag, list, queue, list_cap, front_key, whole_windows, paths, srcidx, t_n);
     else k_list<<<grid_for(n), PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, whole_windows);
     return launch_rc();
 }
@@ -2258,20 +2300,22 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
         mark(1, false);
         return launch_rc();
     }
-    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, stats, hflag, hagg, G);
+    static const int wide_stats_mode = getenv("PTK_WIDE_STATS") ? atoi(getenv("PTK_WIDE_STATS")) : 0;      // diagnostics: 1: stats = {wide node visits, leaf visits}; 2: {sum of the waves' slowest rays, all visits}
+    if (stats) k_intersect<true, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, wide_stats_mode == 2 ? nullptr : stats, hflag, hagg, G);
     else k_intersect<false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, n, d_n, cur, hits, valid, nullptr, ray_total, nullptr, hflag, hagg, G);
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    static const bool wide_stats = getenv("PTK_WIDE_STATS") != nullptr;      // diagnostics: stats = {wide node visits, leaf visits}
+    const bool wide_stats = wide_stats_mode != 0;
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
-    rc = launch_list(S, n, d_n, hflag, hagg, list, queue, 0, wide && !(stats && !wide_stats), cur, G.src, hits.t_n, st);
+    rc = launch_list(S, n, d_n, hflag, hagg, list, queue, n, 0, wide && !(stats && !wide_stats), cur, G.src, hits.t_n, st);
     if (rc) { mark(1, false); return rc; }
-    if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
-    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
-    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    if (wide && stats && wide_stats && wide_lpr == 2) k_traverse_wide<true, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, n, wide_stats_mode);
+    else if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, n, wide_stats_mode);
+    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src, n);
+    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src, n);
     else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg);
+    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg, queue);
     mark(1, false);
     return launch_rc();
 }
@@ -2330,7 +2374,14 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
 template <int MODE, bool GEN>
 static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
                                 const TraceIO& io, float* img, unsigned plane_stride, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
+#ifdef PTK_PERSISTENT
+    static const int cus = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+    static const int per_cu_env = getenv("PTK_PERSIST_BLOCKS") ? atoi(getenv("PTK_PERSIST_BLOCKS")) : 0;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF));
+    const int g = std::min(grid_for(capacity), per_cu * cus);
+#else
     const int g = grid_for(capacity);
+#endif
     if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     else if (compact) k_shade_trace<MODE, GEN, false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
@@ -2390,12 +2441,12 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     if (split) {
         mark(1, true);
         const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
-        if ((rc = launch_list(S, n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1, wide, nxt.paths, nullptr, nxt.hits.t_n, st))) { mark(1, false); return rc; }
-        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
-        else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        if ((rc = launch_list(S, n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, n_bound, 1, wide, nxt.paths, nullptr, nxt.hits.t_n, st))) { mark(1, false); return rc; }
+        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr, n_bound);
+        else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr, n_bound);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
-        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref);
+        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref, ws.queue);
         mark(1, false);
         if ((rc = launch_rc())) return rc;
     }
@@ -2466,8 +2517,8 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid) return PTK_E_BADARG;
     if (n == 0) return 0;
     if (!g_abi_queue) {
-        hipError_t e = hipMalloc(&g_abi_queue, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
-        e = hipMemset(g_abi_queue, 0, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
+        hipError_t e = hipMalloc(&g_abi_queue, 4 * sizeof(unsigned)); if (e != hipSuccess) return (int)e;      // {listed, front, back, -}: see list_pos
+        e = hipMemset(g_abi_queue, 0, 4 * sizeof(unsigned)); if (e != hipSuccess) return (int)e;
     }
     if (n > g_abi_list_cap) {
         for (int** p : {&g_abi_list, &g_abi_hflag, &g_abi_hagg}) { if (*p) (void)hipFree(*p); *p = nullptr; }

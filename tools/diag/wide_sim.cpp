@@ -21,7 +21,7 @@ extern "C" void wide_sim(const uint32_t* nodes, int n_nodes, const float* leaves
         const double inv[3] = {1.0 / rd[0], 1.0 / rd[1], 1.0 / rd[2]};
         float t_min = tmin_init[r];
         const int dir = mtbvh_dir(rd);
-        uint32_t stk[64]; int sp = 0; uint32_t cur = 0; int nv = 0, nl = 0;
+        uint32_t stk[64]; int sp = 0; uint32_t cur = 0; int nv = 0, nl = 0, spmax = 0;
         for (;;) {
             if (!(cur & 0x80000000u)) {
                 ++nv;
@@ -48,7 +48,7 @@ extern "C" void wide_sim(const uint32_t* nodes, int n_nodes, const float* leaves
                 }
                 const int nh = __builtin_popcount(H);
                 for (int c = 0; c < nc; ++c) if (H & (1u << c)) stk[sp + nh - 1 - __builtin_popcount(H & before[c])] = ref[c];
-                sp += nh;
+                sp += nh; if (sp > spmax) spmax = sp;
             } else {
                 ++nl;
                 const float* L = leaves + 16 * (size_t)(cur & 0x7fffffffu);
