@@ -211,15 +211,6 @@ int ptk_get_full_width_bounces(int* out);
  * camera rays hit anything: the camera launch then stores the path state of the hits only, after its trace phase (generateRayFromCamera,
  * pathtrace.cu:120-167, writes every path; a miss is never read again here).  Diagnostic; results never depend on it. */
 int ptk_get_open_scene_hint(int* out);
-/* Test-only: offset k added to the compacted slot in the shading RNG key (pathtrace.cu:363,458,532), and a reset of the radiance
- * buffer.  tests/test_gallery.py renders the reference's gallery/Direct20.png with the slot offsets its GPU build ran with. */
-int ptk_debug_slot_shift(int k);
-int ptk_debug_clear_image(void);
-/* Test-only: the kernels' exact fast paths for IEEE divide / sqrt / 1/sqrt and their packed 3-vector arithmetic (csrc/ptk_device.hpp)
- * against the plain `/`, sqrtf and scalar forms, bit for bit, on n pseudo-random operand sets on the device; bad8 (host) receives
- * the mismatch counts of the eight checks, samples128 (host, optional) the first failing operand sets ([0] = their number, then 8
- * words each: check mask, six operand bit patterns, operand class).  tests/test_gpu_exact_math.py. */
-int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long* bad8, unsigned* samples128);
 /* Host-only description of that partition (no GPU): paths owned by `part`, and the pixel index (x + y*W) of its j-th path. */
 int ptk_partition_count(int W, int H, int n_parts, int part, int tile_rows);
 int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);

@@ -20,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # PTK_FLAVOUR=fma selects the opt-in "reference-device numerics" build (libptk_fma.so: -ffp-contract=fast, like nvcc's -fmad=true);
+# PTK_FLAVOUR=hooks the test-hooks build (libptk_hooks.so: the product sources + include/ptk_test_hooks.h, used by child processes of the tests);
 # anything else is the default bit-exact library.  One flavour per process (the library holds the render context).
 FLAVOUR = os.environ.get("PTK_FLAVOUR", "") or "exact"       # "fma", or the name of a diagnostic build libptk_<name>.so (tools/diag)
 if FLAVOUR != "exact" and not os.path.exists(os.path.join(CSRC, f"libptk_{FLAVOUR}.so")):
@@ -44,8 +45,10 @@ ABI_SYMBOLS = [
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
     "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_shade_binning", "ptk_set_light_fix",
-    "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_get_open_scene_hint", "ptk_debug_slot_shift", "ptk_debug_clear_image", "ptk_debug_exact_math",
+    "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_get_open_scene_hint",
 ]
+# include/ptk_test_hooks.h: exported by libptk_hooks.so (PTK_FLAVOUR=hooks) only, never by the product library
+HOOK_SYMBOLS = ["ptk_debug_slot_shift", "ptk_debug_clear_image", "ptk_debug_exact_math"]
 
 
 class PtkError(RuntimeError):
@@ -56,7 +59,7 @@ class PtkError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libptk.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC, "libptk.so", "libptk_fma.so", "ptk_headless"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", CSRC, "libptk.so", "libptk_fma.so", "libptk_hooks.so", "ptk_headless"], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:], r.stderr[-4000:])
     if r.returncode != 0:
@@ -144,8 +147,9 @@ def _load() -> C.CDLL:
     lib.ptk_set_iteration_sharding.argtypes = [ci, ci]
     lib.ptk_get_full_width_bounces.argtypes = [C.POINTER(ci)]
     lib.ptk_get_open_scene_hint.argtypes = [C.POINTER(ci)]
-    lib.ptk_debug_slot_shift.argtypes = [ci]
-    lib.ptk_debug_exact_math.argtypes = [C.c_ulonglong, C.c_uint, vp, vp]
+    if FLAVOUR == "hooks":
+        lib.ptk_debug_slot_shift.argtypes = [ci, ci]
+        lib.ptk_debug_exact_math.argtypes = [C.c_ulonglong, C.c_uint, vp, vp]
     lib.ptk_timer_stop.argtypes = [C.POINTER(C.c_float)]
     lib.ptk_profile_end.argtypes = [vp, vp]
     lib.ptk_enable_traversal_stats.argtypes = [ci]

@@ -182,29 +182,6 @@ int DevScene::initiate(Scene& scene) {
             if ((rc = upload(&dev_wnodes, wb.nodes))) return rc;
             if ((rc = upload(&dev_wleaves, wb.leaves))) return rc;
             wide_nodes = (int)wb.nodes.size(); wide_depth = wb.depth; wide_stack = wb.max_stack;
-            // traversal-cost table (PTK_OCC_*): how many leaf boxes overlap every cell of a grid over the root box, as round(4 log2(1 + n)).
-            // Read by k_list_sorted only, to order the work list; never by anything that decides a hit.
-            const int R = PTK_OCC_RES;
-            std::vector<uint32_t> cnt((size_t)R * R * R, 0u);
-            const GpuBVHNode& root = scene.gpuBVHNodes[0];
-            const double lo[3] = {root.pMin.x, root.pMin.y, root.pMin.z};
-            double sc[3];
-            for (int a = 0; a < 3; ++a) { const double ext = (double)(a == 0 ? root.pMax.x : (a == 1 ? root.pMax.y : root.pMax.z)) - lo[a]; sc[a] = (ext > 0 && std::isfinite(ext)) ? R / ext : 0.0; }
-            for (const WideLeafHost& L : wb.leaves) {
-                int c0[3], c1[3];
-                for (int a = 0; a < 3; ++a) {
-                    const double x0 = ((double)L.lo[a] - lo[a]) * sc[a], x1 = ((double)L.hi[a] - lo[a]) * sc[a];
-                    c0[a] = std::min(R - 1, std::max(0, (int)std::floor(std::isfinite(x0) ? x0 : 0.0)));
-                    c1[a] = std::min(R - 1, std::max(0, (int)std::floor(std::isfinite(x1) ? x1 : 0.0)));
-                }
-                for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) cnt[((size_t)z * R + y) * R + x]++;
-            }
-            std::vector<uint32_t> occ(8 + (size_t)R * R * R / 4, 0u);
-            const float hdr[8] = {(float)lo[0], (float)lo[1], (float)lo[2], (float)sc[0], (float)sc[1], (float)sc[2], 0.f, 0.f};
-            std::memcpy(occ.data(), hdr, sizeof(hdr));
-            unsigned char* cells = reinterpret_cast<unsigned char*>(occ.data() + 8);
-            for (size_t k = 0; k < cnt.size(); ++k) cells[k] = (unsigned char)std::min(255.0, std::floor(4.0 * std::log2(1.0 + (double)cnt[k]) + 0.5));
-            if ((rc = upload(&dev_occ, occ))) return rc;
         }
     }
     if ((rc = upload(&dev_triv, tv))) return rc;
@@ -219,7 +196,7 @@ int DevScene::initiate(Scene& scene) {
 }
 
 void DevScene::destroy() {
-    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_trie, &dev_wnodes, &dev_wleaves, &dev_occ, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
+    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_trie, &dev_wnodes, &dev_wleaves, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     wide_nodes = 0;
     uploaded = false;

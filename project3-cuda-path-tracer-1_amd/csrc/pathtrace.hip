@@ -15,6 +15,9 @@
 // (chains of dependent loads with ~1 wave per SIMD left) and tile-sharded frames leave most of the 256 CUs idle.
 #include "ptk_internal.h"
 #include "pathtrace.h"
+#ifdef PTK_TEST_HOOKS
+#include "../../include/ptk_test_hooks.h"
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -77,7 +80,7 @@ struct RenderContext {
 } g;
 
 int g_mode_override = -1;               // ptk_set_sample_mode; -1 = follow the `sampleMode` global
-int g_debug_slot_shift = 0;             // ptk_debug_slot_shift: test-only offset of the shading RNG key (tests/test_gallery.py)
+int g_debug_slot_shift = 0, g_debug_slot_shift_deep = 0;      // test hooks (libptk_hooks.so only): offsets of the shading RNG key at depth 0 / depth >= 1; always 0 in the product
 
 template <typename T> int dalloc(T** p, size_t count) {
     *p = nullptr;
@@ -99,7 +102,7 @@ void sync_all() { for (Lane& l : g.lanes) if (l.stream) (void)hipStreamSynchroni
 
 int context_free() {
     sync_all();
-    g_debug_slot_shift = 0;             // a test that died between set and reset must not shift the keys of later renders
+    g_debug_slot_shift = g_debug_slot_shift_deep = 0;      // a test that died between set and reset must not shift the keys of later renders
     for (Lane& l : g.lanes) {
         free_paths(l.bufA); free_paths(l.bufB);
         dfree(l.hits.t_n); dfree(l.hits.p_mat); dfree(l.hits.uv_ids);
@@ -200,7 +203,7 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.ws.valid_b, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.ws.counts, (size_t)g.traceDepth + 2))) return rc;
-    if ((rc = dalloc(&l.ws.queue, 4))) return rc;          // {listed, front, back, -} (ptk_kernels.hip: list_pos)
+    if ((rc = dalloc(&l.ws.queue, 1))) return rc;
     if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
     if ((rc = dalloc(&l.ws.srcidx, (size_t)g.capacity))) return rc;
@@ -210,7 +213,7 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
     if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
     l.ws.seg_done = fold_segments(g.pipeline, g.n_lanes) ? l.seg_done_mem : nullptr;
-    if ((e = hipMemsetAsync(l.ws.queue, 0, 4 * sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(l.ws.queue, 0, sizeof(unsigned), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.counts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(l.ws.hcounts, 0, sizeof(int) * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
     l.ws.ray_total = g.ray_total;
@@ -306,7 +309,7 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     Workspace ws = L.ws;
     ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
     ws.iter_stride = g.n_lanes * g.n_shards;
-    ws.slot_bias += g_debug_slot_shift;
+    ws.dbg_shift0 = g_debug_slot_shift; ws.dbg_shift_deep = g_debug_slot_shift_deep;
     ws.gen_late = g.gen_late;
     const int full = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
     if (use_trace_pipeline()) {
@@ -624,17 +627,19 @@ int ptk_get_full_width_bounces(int* out) {
     *out = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
     return 0;
 }
-/* TEST-ONLY knobs (tests/test_gallery.py: the HIP path against the reference's own gallery pixels).  ptk_debug_slot_shift(k): the
- * shading kernels key their RNG by compacted slot + k (the reference's GPU build flipped a few silhouette pixels per iteration, which
- * shifts every later slot by a small constant; tests/golden/make_gallery_fixture.py).  ptk_debug_clear_image(): zero the radiance
- * planes, so that single iterations can be read back one by one. */
-int ptk_debug_slot_shift(int k) { g_debug_slot_shift = k; invalidate_graphs(); return 0; }
+#ifdef PTK_TEST_HOOKS
+/* TEST-ONLY (include/ptk_test_hooks.h; compiled into libptk_hooks.so only).  ptk_debug_slot_shift(k0, k1): the shading kernels key their RNG by
+ * compacted slot + k0 at depth 0 and + k1 at depth >= 1 (the reference's GPU build flipped a few silhouette hit / miss decisions per iteration,
+ * which shifts every later slot of that depth by a small constant; tests/golden/make_gallery_fixture.py).  ptk_debug_clear_image(): zero the
+ * radiance planes, so that single iterations can be read back one by one. */
+int ptk_debug_slot_shift(int k0, int k1) { g_debug_slot_shift = k0; g_debug_slot_shift_deep = k1; invalidate_graphs(); return 0; }
 int ptk_debug_clear_image(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();
     const int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
     return rc ? rc : rc_of(hipDeviceSynchronize());      // null-stream clear vs the lanes' non-blocking streams
 }
+#endif
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
     g.pipeline = which;

@@ -287,9 +287,6 @@ struct DevNode {
 //              ref = wide-node index, or 0x80000000 | leaf-record index.
 // Leaf record, 64 B = 4 x uint4: exact fp32 box of the reference's leaf node, the triangle in edge form (as DevTriE), its index.
 struct WideLeaf { float lo[3], hi[3], v0[3], e1[3], e2[3]; int tri; };
-// Traversal-cost table for ordering the BVH work list (k_list_sorted, ptk_kernels.hip): a PTK_OCC_RES^3 grid over the mesh's root box, one
-// byte per cell = round(4 log2(1 + triangles whose leaf box overlaps the cell)).  It only ever decides in which ORDER listed rays are walked.
-#define PTK_OCC_RES 32
 struct DevTriE { float v0[3], e1[3], e2[3], pad[3]; };                          // 48 B: v0 and the two edges (e = v - v0 as in Bounds3.hpp:300-301)
 struct DevTriV { float v0[3], v1[3], v2[3]; };                                  // 36 B, positions (attribute interpolation, light sampling)
 struct DevTriA { float n0[3], n1[3], n2[3]; float t0[2], t1[2], t2[2]; int geomIdx; float tangent[3]; };  // 76 B, shading attributes
@@ -306,7 +303,6 @@ struct SceneView {
     const DevTriE* trie;         // traversal form of the triangles
     const uint4* wnodes;         int n_wnodes;   // 8-wide collapsed form of the same tree (WideNode, 9 x uint4 = 144 B each); null = none
     const uint4* wleaves;        // WideLeaf records (4 x uint4 each), children of one wide node consecutive
-    const uint32_t* occ;         // traversal-cost table (PTK_OCC_*): 8 header words {lo.xyz, cells / extent .xyz, 0, 0}, then PTK_OCC_RES^3 bytes; null = none
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;
     const DevTex* tex;           const float* texels;   int env_tex;     // env_tex = envMapID (-1: none)

@@ -33,7 +33,6 @@ inline SceneView dev_view(const ::Scene& s) {
     d.trie = (const DevTriE*)t.dev_trie;
     d.wnodes = (const uint4*)t.dev_wnodes;       d.n_wnodes = t.wide_nodes;
     d.wleaves = (const uint4*)t.dev_wleaves;
-    d.occ = (const uint32_t*)t.dev_occ;
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();
     d.tex = (const DevTex*)t.dev_textures;       d.texels = (const float*)t.dev_texture_data; d.env_tex = t.envMapID;
@@ -58,6 +57,7 @@ struct Workspace {               // per-render-context scratch, device memory
     int spp = 1;                 // samples (iterations) per launch
     int slot_bias = 0;           // added to the compacted slot in the shading RNG key: part * W * H * spp under the tile partition, so
                                  // that two ranks never share a random stream (0 on one GPU = the reference's key)
+    int dbg_shift0 = 0, dbg_shift_deep = 0;   // test hooks only (libptk_hooks.so, include/ptk_test_hooks.h): extra key offset at depth 0 / depth >= 1; 0 in the product
     // segmented path streams (default): physical slot of every dense path, window prefix and first-window tables
     int* srcidx = nullptr; int* seg_pref = nullptr; int* seg_first = nullptr;
     int* seg_done = nullptr;     // blocks of the running shading kernel that have published their survivor count (segments_tail); null:

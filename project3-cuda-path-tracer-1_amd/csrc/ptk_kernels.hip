@@ -23,6 +23,9 @@
 //     the intersect flags + per-block aggregates, survivors are written once, block-locally, and found again through the
 //     window prefix (gather_source).  See DESIGN.md section 4/5.
 #include "ptk_internal.h"
+#ifdef PTK_TEST_HOOKS
+#include "../../include/ptk_test_hooks.h"
+#endif
 
 using namespace ptk;
 
@@ -504,147 +507,29 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_list(int n_arg, const int* __rest
     int n = d_n ? *d_n : n_arg;
     if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;      // fused pipeline: flags live at physical slots, every slot of a window is written
     const int b = blockIdx.x;
-    if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0) { list_count[0] = 0u; list_count[1] = 0u; list_count[2] = 0u; } return; }
+    if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0) *list_count = 0u; return; }
     const int i = b * PTK_BLOCK + threadIdx.x;
     const int flag = (i < n) ? heavy_flag[i] : 0;
     int total;
     const int local = block_excl_prefix(flag, total);
     const int prior = prior_blocks(heavy_agg, b);
     if (flag) list[prior + local] = i;
-    if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) { list_count[0] = (unsigned)(prior + total); list_count[1] = (unsigned)(prior + total); list_count[2] = 0u; }      // (all "front": list_pos(j) = j)
+    if (threadIdx.x == 0 && b == (n - 1) / PTK_BLOCK) *list_count = (unsigned)(prior + total);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// k_list_sorted: the same work list, ordered by PREDICTED TRAVERSAL COST inside chunks of PTK_LIST_BLOCK stream slots (round 4).
-//
-// A wave of k_traverse_wide serves 64 / LPR rays and runs for its slowest one; in path order the visit counts of neighbouring rays are
-// unrelated (bunny scene: mean 9.7 visits per listed ray, maximum 60-90) and ~35 % of the lane slots do work.  The ORDER of the list is
-// free: every result goes to its ray's own slot and no RNG key depends on it.  tools/diag/coherence_sim.py models the walk on the CPU
-// (per-ray visit counts over the host copy of the wide tree; cost of an order = sum over waves of the slowest ray): spatial keys (octant,
-// Morton cell of the entry point or of the chord's midpoint) buy 20 % sorted globally and under 10 % inside chunks; a cost PREDICTOR works
-// as well inside chunks of a few hundred rays as globally, because what it fixes is the mix of cheap and expensive rays in a wave, not
-// locality: children of the root node the ray hits x 3 + the traversal-cost table (PTK_OCC_*) sampled at 16 points of the ray's chord
-// through the root box — 0.71-0.74 of the unsorted cost (perfect knowledge of the visit counts: 0.36-0.42).  One thread per listed ray,
-// approximate reciprocals (nothing here decides a hit), ~350 instructions; LDS counting sort, heaviest first.
-// ------------------------------------------------------------------------------------------------------------------
-#define PTK_LIST_SLOTS 1024       // stream slots per block of k_list_sorted (the chunk inside which rays are ordered)
-#define PTK_LIST_KEYS 128
-// list_count[0..2] = {rays listed by the plain k_list, FRONT rays, BACK rays}.  k_list_sorted places the rays whose key reaches `front_key` from
-// list[0] upwards and the others from list[list_cap - 1] downwards (one atomic per block and class; the order of the chunks is free), so that
-// the rays with the long dependent chains are all in flight from the first moment — the walk's duration is its slowest ray's chain, not its
-// instruction count.  k_finalize / k_finalize2 clear the counters.  Listed ray j of the walk sits at list[list_pos(j)].
-__device__ __forceinline__ int list_pos(int j, int n_front, int n_back, int list_cap) { return j < n_front ? j : list_cap - n_back + (j - n_front); }
-__global__ void __launch_bounds__(PTK_BLOCK) k_list_sorted(SceneView S, int n_arg, const int* __restrict__ d_n, const int* __restrict__ heavy_flag,
-                                                            int* __restrict__ list, unsigned* __restrict__ list_count, int list_cap, int front_key,
-                                                            int whole_windows, PtkPaths paths, const int* __restrict__ srcidx, const float* __restrict__ t_n) {
-    constexpr int NT = PTK_BLOCK, PER = PTK_LIST_SLOTS / NT;
-    __shared__ int s_idx[PTK_LIST_SLOTS];
-    __shared__ int s_kp[PTK_LIST_SLOTS];
-    __shared__ int s_hist[PTK_LIST_KEYS], s_off[PTK_LIST_KEYS];
-    __shared__ int s_cnt, s_half, s_base[3];
-    int n = d_n ? *d_n : n_arg;
-    if (whole_windows) n = (n + PTK_BLOCK - 1) / PTK_BLOCK * PTK_BLOCK;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (b * PTK_LIST_SLOTS >= n) return;
-    if (tid == 0) s_cnt = 0;
-    if (tid < PTK_LIST_KEYS) s_hist[tid] = 0;
-    __syncthreads();
-    // the chunk's listed rays -> s_idx (one LDS atomic per wave and pass; their order is free)
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = b * PTK_LIST_SLOTS + k * NT + tid;
-        const int flag = (i < n) ? heavy_flag[i] : 0;
-        const unsigned long long bal = __ballot(flag != 0);
-        int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&s_cnt, __popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (flag) s_idx[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-    }
-    __syncthreads();
-    const int total = s_cnt;
-    const float* hdr = reinterpret_cast<const float*>(S.occ);
-    const float lx = hdr[0], ly = hdr[1], lz = hdr[2], sx = hdr[3], sy = hdr[4], sz = hdr[5];
-    const unsigned char* cells = reinterpret_cast<const unsigned char*>(S.occ + 8);
-    const uint4* np = S.wnodes;
-    const uint4 q0 = np[0];
-    const int nc = (int)(q0.w >> 24);
-    for (int j = tid; j < total; j += NT) {                      // one thread per listed ray: predicted traversal cost
-        const int ray = s_idx[j];
-        const int src = srcidx ? srcidx[ray] : ray;
-        const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
-        const float t0 = t_n[4 * (size_t)ray];
-        const float tmax = t0 > 0.f ? t0 : FLT_MAX;
-        const float ix = __builtin_amdgcn_rcpf(d4.x), iy = __builtin_amdgcn_rcpf(d4.y), iz = __builtin_amdgcn_rcpf(d4.z);
-        // (a) children of the root node whose dequantised box the ray hits before tmax
-        const float ex = __uint_as_float((q0.w & 0xffu) << 23), ey = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), ez = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
-        const float bx = (__uint_as_float(q0.x) - o4.x) * ix, by = (__uint_as_float(q0.y) - o4.y) * iy, bz = (__uint_as_float(q0.z) - o4.z) * iz;
-        const float ax = ex * ix, ay = ey * iy, az = ez * iz;
-        int hits = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint4 ch = np[1 + c];
-            const float x0 = __builtin_fmaf((float)(ch.x & 0xffu), ax, bx), x1 = __builtin_fmaf((float)(ch.x >> 24), ax, bx);
-            const float y0 = __builtin_fmaf((float)((ch.x >> 8) & 0xffu), ay, by), y1 = __builtin_fmaf((float)(ch.y & 0xffu), ay, by);
-            const float z0 = __builtin_fmaf((float)((ch.x >> 16) & 0xffu), az, bz), z1 = __builtin_fmaf((float)((ch.y >> 8) & 0xffu), az, bz);
-            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            hits += (c < nc && tn <= fminf(tf, tmax) && tf >= 0.f) ? 1 : 0;
-        }
-        // (b) the cost table along the ray's chord through the root box, clipped by the analytic hit
-        const float R = (float)PTK_OCC_RES;
-        const float hx = lx + R * __builtin_amdgcn_rcpf(sx), hy = ly + R * __builtin_amdgcn_rcpf(sy), hz = lz + R * __builtin_amdgcn_rcpf(sz);
-        const float u0 = (lx - o4.x) * ix, u1 = (hx - o4.x) * ix, v0 = (ly - o4.y) * iy, v1 = (hy - o4.y) * iy, w0 = (lz - o4.z) * iz, w1 = (hz - o4.z) * iz;
-        const float tn = fmaxf(fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fminf(w0, w1)), 0.f);
-        const float tf = fminf(fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)), tmax);
-        const float dt = (tf - tn) * (1.0f / 16.0f);
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float t = __builtin_fmaf(dt, (float)k + 0.5f, tn);
-            const float px = (__builtin_fmaf(d4.x, t, o4.x) - lx) * sx, py = (__builtin_fmaf(d4.y, t, o4.y) - ly) * sy, pz = (__builtin_fmaf(d4.z, t, o4.z) - lz) * sz;
-            const int cx = (int)fminf(fmaxf(px, 0.f), R - 1.f), cy = (int)fminf(fmaxf(py, 0.f), R - 1.f), cz = (int)fminf(fmaxf(pz, 0.f), R - 1.f);      // (fmaxf drops a NaN)
-            sum += cells[(cz * PTK_OCC_RES + cy) * PTK_OCC_RES + cx];
-        }
-        const int key = min(PTK_LIST_KEYS - 1, 3 * hits + (sum >> 2));
-        s_kp[j] = (key << 16) | atomicAdd(&s_hist[key], 1);     // (the order inside a bucket is free)
-    }
-    __syncthreads();
-    // start of every bucket, heaviest first: s_off[r] = rays with a key above 127 - r; the block's FRONT rays = those with key >= front_key
-    if (tid < PTK_LIST_KEYS) {
-        const int v = s_hist[PTK_LIST_KEYS - 1 - tid];
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (tid == 63) s_half = incl;
-        s_off[tid] = incl - v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int fk = min(max(front_key, 0), PTK_LIST_KEYS);    // front = keys fk .. 127 = reversed buckets 0 .. 127 - fk
-        const int rf = PTK_LIST_KEYS - fk;                       // number of reversed buckets in front
-        const int nfb = rf <= 0 ? 0 : (rf >= PTK_LIST_KEYS ? total : s_off[rf] + (rf >= 64 ? s_half : 0));
-        s_base[0] = nfb;
-        s_base[1] = nfb ? (int)atomicAdd(&list_count[1], (unsigned)nfb) : 0;
-        s_base[2] = (total - nfb) ? (int)atomicAdd(&list_count[2], (unsigned)(total - nfb)) : 0;
-    }
-    __syncthreads();
-    const int nfb = s_base[0], front_base = s_base[1], back_base = s_base[2];
-    for (int j = tid; j < total; j += NT) {
-        const int kp = s_kp[j], key = kp >> 16, r = PTK_LIST_KEYS - 1 - key;
-        const int rank = s_off[r] + (r >= 64 ? s_half : 0) + (kp & 0xffff);
-        const int ray = s_idx[j];
-        if (rank < nfb) list[front_base + rank] = ray;
-        else list[list_cap - 1 - (back_base + (rank - nfb))] = ray;
-    }
-}
-
+// (round 4, measured and removed — commits 85deb16 / the one after e1334c2: the same list ordered by PREDICTED TRAVERSAL COST, k_list_sorted.
+// Root children hit x 3 + a 32^3 leaf-density table sampled along the ray's chord, counting-sorted inside chunks of 1 024 stream slots, the
+// heaviest quarter placed at the front of the list so that the long chains start first.  The walk's busy lane share rose from 0.42 to 0.55
+// (quads) / 0.36 to 0.48 (pairs) — PTK_WIDE_STATS=2, profiles/r4_lane_busy_sorted_list.txt, exactly what the CPU model tools/diag/coherence_sim.py
+// predicts — and k_traverse_wide went from 75.2 to 70.1 us: its duration is the dependent chain of its slowest ray, not its instruction count.
+// With the 13-18 us the sort kernel costs the iteration was 4-10 % SLOWER at 800 x 800 and unchanged at 2048 x 2048 (profiles/r4_ab_sorted_list*.txt).)
 // BVH traversal of the listed rays, one per lane (pathtrace.cu:236-279).  A triangle winner is parked as (u, v, t, tri) in
 // the ray's uv_ids slot with flag PTK_VALID_TRI; k_finalize expands it (and clears the list counter for the next bounce).
 template <bool STATS>
 __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                          PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
                                                          const int* __restrict__ srcidx) {
-    const int m = (int)(list_count[1] + list_count[2]);       // (always in path order here: k_list)
+    const int m = (int)*list_count;
     const int j = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (blockIdx.x * PTK_BLOCK >= m) return;
     unsigned nv = 0, nt = 0;
@@ -756,11 +641,11 @@ __device__ __forceinline__ int wide_leaf_visit(const uint4 l0, const uint4 l1, c
 template <bool STATS, int LPR>       // LPR lanes per ray (4: shortest chain; 2: fewer instructions per ray, see the header comment)
 __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
-                                                              const int* __restrict__ srcidx, int list_cap, int stats_mode = 0) {
+                                                              const int* __restrict__ srcidx, int stats_mode = 0) {
     constexpr int RAYS = PTK_WIDE_BLOCK / LPR, NCH = 8 / LPR;     // rays per block; children per lane
     __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
     __shared__ unsigned s_stack[RAYS * PTK_WIDE_STRIDE];
-    const int n_front = (int)list_count[1], n_back = (int)list_count[2], m = n_front + n_back;
+    const int m = (int)*list_count;
     if (blockIdx.x * RAYS >= m) return;
     const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
     if (PTK_WIDE_TOP > 0) {
@@ -772,7 +657,7 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
     const int j = blockIdx.x * RAYS + threadIdx.x / LPR;
     unsigned nv = 0, nt = 0;
     if (j < m) {
-        const int ray = list[list_pos(j, n_front, n_back, list_cap)];
+        const int ray = list[j];
         const int src = srcidx ? srcidx[ray] : ray;
         const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
         const float t0 = hits.t_n[4 * (size_t)ray];
@@ -887,10 +772,9 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
 }
 
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits,
-                                                         int* __restrict__ valid, int* __restrict__ agg, unsigned* __restrict__ list_count) {
+                                                         int* __restrict__ valid, int* __restrict__ agg) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
-    if (b == 0 && threadIdx.x < 3) list_count[threadIdx.x] = 0u;       // the walk is over: clear the work-list counters for the next bounce
     if (b * PTK_BLOCK >= n) return;
     const int i = b * PTK_BLOCK + threadIdx.x;
     int flag = 0;
@@ -918,11 +802,9 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
 // PTK_VALID_TRI; writes the hit rank of every slot (hr: >= 0 rank among the hits of its window, -1 miss, -2 empty) and the window's
 // hit count, from which its last block builds hit_pref (a triangle hit changes the ranks the shading keys are made of).
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits, const int* __restrict__ valid,
-                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref,
-                                                          unsigned* __restrict__ list_count) {
+                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
-    if (b == 0 && threadIdx.x < 3) list_count[threadIdx.x] = 0u;       // the walk is over: clear the work-list counters for the next bounce
     if (b * PTK_BLOCK >= n) {
         if (n <= 0 && b == 0 && threadIdx.x < 8) hit_pref[threadIdx.x] = 0;
         return;
@@ -1586,14 +1468,11 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         return;
     }
     const GeomStage gs = stage_geoms(S);                           // the trace phase always needs the primitives; MIS / DIRECT shading too
-#ifdef PTK_PERSISTENT
-    // A/B build (tools/diag/build_variant.sh persist -DPTK_PERSISTENT): an occupancy-sized grid whose blocks loop over the windows b, b + G, ...;
-    // the primitives are staged once per block (the materials share LDS with the pair list and are staged per window)
-    for (int b = blockIdx.x; b * NT < n; b += gridDim.x) {
-    __syncthreads();                                               // the previous window's LDS reads are over
-#else
+    // (round 4, measured and removed: an occupancy-sized grid whose blocks loop over the windows b, b + G, ... and stage the primitives once —
+    // cornell 12.40 -> 8.74 Grays/s one iteration at a time, 23.17 -> 12.74 with three in flight, profiles/r4_ab_persistent_grid.txt: a resident
+    // block that loops keeps its slot through every phase of its next window, where the dispatcher hands a finished block's slot to whichever
+    // launch has work, and with several lanes the second lane's grid cannot start before the first one's blocks have looped to the end)
     { const int b = blockIdx.x;
-#endif
     if (tid < NT / 64) { s_alive[tid] = 0ull; if (DEFER_NEE) { s_occ[tid] = 0ull; s_anyreq = 0; } }      // (published by the barrier in stage_materials)
     const int i = b * NT + tid;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1959,6 +1838,7 @@ struct TailArgs {
     PtkPaths cur, nxt;                       // cur: the stream entering bounce depth0 (windowed if G.pref != null)
     Gather G;
     float* img; unsigned plane_stride; int spp, slot_bias;
+    int dbg_shift0, dbg_shift_deep;          // test hooks only (0 in the product): extra key offset at depth 0 / depth >= 1
     unsigned long long* ray_total;
     int* iter_advance; int iter_stride;
     // fused pipeline: bounce depth0 has been traced already (k_shade_trace); its hit records / ranks sit at the paths' physical slots
@@ -2046,7 +1926,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
             }
             int total;
             const int local = block_excl_prefix_n<NT>(flag, total);
-            if (flag) alive = shade_path<MODE>(S, gs, mt, iter, hits_before + local + A.slot_bias, depth, h, p, img);
+            if (flag) alive = shade_path<MODE>(S, gs, mt, iter, hits_before + local + A.slot_bias + (depth >= 1 ? A.dbg_shift_deep : A.dbg_shift0), depth, h, p, img);
             int total2;
             const int local2 = block_excl_prefix_n<NT>(alive, total2);
             if (alive) {
@@ -2103,6 +1983,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_sum_planes(const float* __restric
     out[i] = s;
 }
 
+#ifdef PTK_TEST_HOOKS
 // ------------------------------------------------------------------------------------------------------------------
 // TEST-ONLY: the exact fast paths of ptk_device.hpp (div_exact / inv_exact / sqrt_exact / inv_sqrt_exact / div3_exact / box_test / sphere_test,
 // the packed dot / normalize / xform_*) against the plain IEEE forms (`/`, sqrtf, scalar arithmetic in glm's order), bit for bit,
@@ -2184,6 +2065,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_exact_check(unsigned long long n,
         }
     }
 }
+
+#endif // PTK_TEST_HOOKS
 
 inline int grid_for(int n) { return (n + PTK_BLOCK - 1) / PTK_BLOCK; }
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -2276,16 +2159,6 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
     return launch_rc();
 }
 
-// the BVH work list: ordered by predicted traversal cost when the wide walk runs (k_list_sorted; PTK_LIST_SORT=0: path order, for A/B runs)
-static int launch_list(const SceneView& S, int n, const int* d_n, const int* hflag, const int* hagg, int* list, unsigned* queue, int list_cap, int whole_windows,
-                       bool wide, PtkPaths paths, const int* srcidx, const float* t_n, hipStream_t st) {
-    static const bool sorted = !(getenv("PTK_LIST_SORT") && atoi(getenv("PTK_LIST_SORT")) == 0);
-    static const int front_key = getenv("PTK_LIST_FRONT_KEY") ? atoi(getenv("PTK_LIST_FRONT_KEY")) : 20;      // (A/B knob; 0: one class, only the order inside the chunks)
-    if (sorted && wide && S.occ) k_list_sorted<<<(n + PTK_LIST_SLOTS - 1) / PTK_LIST_SLOTS, PTK_BLOCK, 0, st>>>(S, n, d_n, hflag, list, queue, list_cap, front_key, whole_windows, paths, srcidx, t_n);
-    else k_list<<<grid_for(n), PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, whole_windows);
-    return launch_rc();
-}
-
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
@@ -2306,16 +2179,16 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     int rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     const bool wide_stats = wide_stats_mode != 0;
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
-    rc = launch_list(S, n, d_n, hflag, hagg, list, queue, n, 0, wide && !(stats && !wide_stats), cur, G.src, hits.t_n, st);
-    if (rc) { mark(1, false); return rc; }
-    if (wide && stats && wide_stats && wide_lpr == 2) k_traverse_wide<true, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, n, wide_stats_mode);
-    else if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, n, wide_stats_mode);
-    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src, n);
-    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src, n);
+    k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0);
+    rc = launch_rc(); if (rc) { mark(1, false); return rc; }
+    if (wide && stats && wide_stats && wide_lpr == 2) k_traverse_wide<true, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
+    else if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
+    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg, queue);
+    k_finalize<<<g, PTK_BLOCK, 0, st>>>(S, n, d_n, hits, valid, agg);
     mark(1, false);
     return launch_rc();
 }
@@ -2347,7 +2220,8 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
     mark(2, true);
     const bool fold = seg && ws.seg_done != nullptr;         // the shading kernel's last block does the window bookkeeping itself
     const SegTail tail = {fold ? ws.seg_done : nullptr, ws.seg_pref, ws.seg_first, ws.counts + depth + 1, last_bounce ? ws.iter_dev : nullptr, ws.iter_stride};
-    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp, ws.slot_bias, st,
+    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp,
+                            ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0), st,
                             G.src, seg ? nxt : PtkPaths{nullptr, nullptr, nullptr}, tail);
     mark(2, false);
     if (rc || fold) return rc;
@@ -2374,14 +2248,7 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
 template <int MODE, bool GEN>
 static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
                                 const TraceIO& io, float* img, unsigned plane_stride, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
-#ifdef PTK_PERSISTENT
-    static const int cus = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
-    static const int per_cu_env = getenv("PTK_PERSIST_BLOCKS") ? atoi(getenv("PTK_PERSIST_BLOCKS")) : 0;
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF));
-    const int g = std::min(grid_for(capacity), per_cu * cus);
-#else
     const int g = grid_for(capacity);
-#endif
     if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     else if (compact) k_shade_trace<MODE, GEN, false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
     else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
@@ -2419,18 +2286,19 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     const SegTail2 tail = {ws.seg_done, ws.seg_pref, ws.seg_first, split ? nullptr : ws.hit_pref, ws.counts + dt, last ? ws.iter_dev : nullptr, ws.iter_stride, ws.ray_total,
                            !split ? ws.seg_first_h : nullptr, !split ? ws.hcounts + dt : nullptr};
     const int depth = dt - 1;           // RNG key depth of the bounce being shaded
+    const int sbias = ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0);
     mark(gen ? 0 : 2, true);
     int rc;
     if (gen) {
         switch (mode) {                 // (the mode only matters for the hit-record layout the next launch expects: same kernel body)
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;   // (the MIS layouts carry the origin)
-        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;   // (the MIS layouts carry the origin)
+        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
         }
     } else {
         switch (mode) {
-        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
-        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, ws.slot_bias, tail, st); break;
+        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
+        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
         default: rc = PTK_E_BADARG;
         }
     }
@@ -2441,12 +2309,13 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     if (split) {
         mark(1, true);
         const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
-        if ((rc = launch_list(S, n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, n_bound, 1, wide, nxt.paths, nullptr, nxt.hits.t_n, st))) { mark(1, false); return rc; }
-        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr, n_bound);
-        else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr, n_bound);
+        k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1);
+        if ((rc = launch_rc())) { mark(1, false); return rc; }
+        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
-        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref, ws.queue);
+        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref);
         mark(1, false);
         if ((rc = launch_rc())) return rc;
     }
@@ -2474,7 +2343,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     A.hcounts = ws.hcounts;
     const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
-    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias;
+    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias; A.dbg_shift0 = ws.dbg_shift0; A.dbg_shift_deep = ws.dbg_shift_deep;
     A.ray_total = ws.ray_total; A.iter_advance = ws.iter_dev; A.iter_stride = ws.iter_stride;
     switch (mode) {
     case PTK_MODE_BSDF: k_tail<PTK_MODE_BSDF><<<1, PTK_TAIL_BLOCK, stage_bytes(S), st>>>(S, A); break;
@@ -2517,8 +2386,8 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid) return PTK_E_BADARG;
     if (n == 0) return 0;
     if (!g_abi_queue) {
-        hipError_t e = hipMalloc(&g_abi_queue, 4 * sizeof(unsigned)); if (e != hipSuccess) return (int)e;      // {listed, front, back, -}: see list_pos
-        e = hipMemset(g_abi_queue, 0, 4 * sizeof(unsigned)); if (e != hipSuccess) return (int)e;
+        hipError_t e = hipMalloc(&g_abi_queue, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
+        e = hipMemset(g_abi_queue, 0, sizeof(unsigned)); if (e != hipSuccess) return (int)e;
     }
     if (n > g_abi_list_cap) {
         for (int** p : {&g_abi_list, &g_abi_hflag, &g_abi_hagg}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -2575,6 +2444,7 @@ int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char*
     return launch_rc();
 }
 
+#ifdef PTK_TEST_HOOKS
 /* test-only: see k_exact_check.  bad8 (host): mismatch counts of the 8 checks over n pseudo-random operand sets */
 int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long* bad8, unsigned* samples128) {
     if (!bad8 || n == 0 || n > (1ull << 36)) return PTK_E_BADARG;
@@ -2593,6 +2463,7 @@ int ptk_debug_exact_math(unsigned long long n, unsigned seed, unsigned long long
     (void)hipFree(d);
     return hip_rc(e);
 }
+#endif // PTK_TEST_HOOKS
 
 #ifdef PTK_PHASE_TIMING
 /* diagnostic build only: out[2][8] = cycles per phase summed over all waves ([7] = wave visits) for k_intersect (0) and

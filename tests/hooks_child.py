@@ -1,0 +1,56 @@
+"""Child process of the tests that need the TEST HOOKS (include/ptk_test_hooks.h): it loads libptk_hooks.so (PTK_FLAVOUR=hooks is set by the
+caller) — the product sources plus the ptk_debug_* entry points, which libptk.so does not export — and writes its result to an .npz.
+    python hooks_child.py exact_math <out.npz> <seed>
+    python hooks_child.py gallery <out.npz> <Direct|BSDF|MIS>      the 20 iterations of scenes/mis_test2.txt, iteration by iteration, with the fixture's
+                                                                slot offsets (depth 0: slot_shift, depth >= 1: slot_shift_deep), summed in iteration order"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    task, out = sys.argv[1], sys.argv[2]
+    import torch
+    torch.cuda.set_device(0)
+    ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
+    assert ptk.FLAVOUR == "hooks", ptk.FLAVOUR
+    if task == "exact_math":
+        bad = np.zeros(8, np.uint64); smp = np.zeros(128, np.uint32)
+        rc = ptk.lib.ptk_debug_exact_math(C.c_ulonglong(1 << 28), int(sys.argv[3]), bad.ctypes.data, smp.ctypes.data)
+        np.savez(out, rc=np.array(rc), bad=bad, smp=smp)
+        return
+    if task == "gallery":
+        import test_gallery as tg
+        name = sys.argv[3]
+        g = tg._fixture()
+        t0, t1 = g["slot_shift"].astype(np.int32), g["slot_shift_deep"].astype(np.int32)
+        W = tg.W
+        s = ptk.Scene(tg.SCENE)
+        assert (s.width, s.height, s.trace_depth) == (W, W, 8)
+        r = ptk.Renderer(s, tg.MODES[name])
+        acc = np.zeros((W, W, 3), np.float32)
+        for it in range(1, 21):
+            one = np.zeros((W, W, 3), np.float32)
+            for k0, k1 in np.unique(np.stack([t0[it], t1[it]], axis=1), axis=0):
+                assert ptk.lib.ptk_debug_slot_shift(int(k0), int(k1)) == 0
+                assert ptk.lib.ptk_debug_clear_image() == 0
+                r.iterate(it)
+                rows = (t0[it] == k0) & (t1[it] == k1)
+                one[rows] = r.image().reshape(W, W, 3)[rows]
+            acc += one
+        ptk.lib.ptk_debug_slot_shift(0, 0)
+        r.close(); s.close()
+        np.savez(out, acc=acc)
+        return
+    raise SystemExit("unknown task " + task)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,22 @@ def test_header_symbols_exported(ptk):
     assert declared == set(ptk.ABI_SYMBOLS), declared ^ set(ptk.ABI_SYMBOLS)
 
 
+def test_test_hooks_are_not_in_the_product_library(ptk):
+    """VERDICT r3 #9: the ptk_debug_* entry points (include/ptk_test_hooks.h) are compiled into libptk_hooks.so only."""
+    import subprocess
+    prod = subprocess.run(["nm", "-D", "--defined-only", ptk.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ptk_debug" not in prod
+    assert "ptk_debug" not in open(os.path.join(ROOT, "include", "ptk.h")).read()
+    hooks = os.path.join(os.path.dirname(ptk.LIB_PATH), "libptk_hooks.so")
+    assert os.path.exists(hooks), "make -C csrc libptk_hooks.so"
+    out = subprocess.run(["nm", "-D", "--defined-only", hooks], capture_output=True, text=True).stdout
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ptk_test_hooks.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(ptk_debug_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(ptk.HOOK_SYMBOLS), declared ^ set(ptk.HOOK_SYMBOLS)
+    for sym in sorted(declared | set(ptk.ABI_SYMBOLS)):
+        assert (" T " + sym) in out, sym
+
+
 def test_every_entry_point_cites_the_reference():
     hdr = open(os.path.join(ROOT, "include", "ptk.h")).read()
     for ref in ("pathtrace.cu:135-163", "pathtrace.cu:169-346", "pathtrace.cu:614-631", "pathtrace.cu:348-588",

