@@ -158,6 +158,12 @@ int ptk_pathtrace_free(void);                           /* pathtraceFree(), path
 int ptk_pathtrace(unsigned char* pbo, int frame, int iter);
 int ptk_set_sample_mode(int mode);                      /* `extern SampleMode sampleMode`, main.cpp:20 / pathtrace.cu:23 */
 int ptk_get_sample_mode(void);
+/* Tiles in flight (1..16, default 1 = off; before ptk_pathtrace_init; not combined with iterations in flight, the tile partition or samples
+ * per launch; needs the fused pipeline 0 / 10).  Every iteration is rendered as K bands of pixel rows on K streams — band k of iteration i beside
+ * band k - 1 of iteration i + 1 — so K launches are in flight like with K iterations in flight, but every pixel still receives its iterations in
+ * order and every path keeps the reference's RNG key (pathtrace.cu:458,532: a band's compacted slots continue those of the bands above it): the
+ * image is BIT-IDENTICAL to the default's, i.e. to the reference's own accumulation order (pathtrace.cu:697-810). */
+int ptk_set_tiles_in_flight(int tiles);
 /* Iterations in flight (1..16, default 1; set before ptk_pathtrace_init).  With L > 1, iteration `it` runs on lane
  * (it-1) % L (own stream, buffers and radiance plane), so consecutive ptk_pathtrace calls overlap on the GPU.  Every
  * iteration is computed exactly as with L = 1; only the order of the per-pixel additions changes: plane l sums

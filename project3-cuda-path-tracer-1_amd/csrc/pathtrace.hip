@@ -53,6 +53,14 @@ struct Lane {
     int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
     bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
     int fresh_hint = 0;                 // iterations enqueued on this lane since the hint was reset (read-backs every iteration at first)
+    // what this lane renders: the whole frame / this rank's tiles (iterations in flight), or ONE band of rows (tiles in flight)
+    int n_parts = 1, part = 0, tile_rows = 1, n_pix = 0, capacity = 0;
+    int full_bounces = 0;               // bounces enqueued at full width; the rest of an iteration runs in k_tail (sparse_tail())
+    int gen_late = 0;                   // open scene (fewer than ~half of the camera rays hit, learnt like full_bounces): the camera launch stores the hits' path state only
+    // tiles in flight: cumulative hit counts [PTK_CUM_RING][traceDepth + 2] (ptk_internal.h: Workspace::cum_*) and one event per ring slot,
+    // recorded after this lane's iteration i in slot i % PTK_CUM_RING
+    int* cum = nullptr;
+    hipEvent_t ring_ev[PTK_CUM_RING] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct RenderContext {
@@ -69,9 +77,9 @@ struct RenderContext {
     int pipeline = 0, n_lanes = 1, spp = 1, n_pix = 0;
     bool use_graph = false;
     int last_lane = 0;
-    int full_bounces = 0;               // bounces enqueued at full width; the rest of an iteration runs in k_tail (sparse_tail())
-    int gen_late = 0;                   // open scene (fewer than ~half of the camera rays hit, learnt like full_bounces): the camera launch stores the hits' path state only
-    int hint_mode = -1;                 // sample mode the full_bounces hint was learnt under
+    int hint_mode = -1;                 // sample mode the lanes' full_bounces / gen_late hints were learnt under
+    int want_tiles = 1;                 // ptk_set_tiles_in_flight
+    bool tiles = false;                 // tiles in flight: the lanes are bands of rows of ONE iteration stream (see render_iteration)
     int n_shards = 1, shard = 0;        // iteration sharding (ptk_set_iteration_sharding): call `step` renders iteration (step-1)*n_shards + shard + 1
     bool live = false;
     // C++ API (pathtrace.h): scene->state.image is made current on demand (pathtraceResolve), not after every call
@@ -110,7 +118,8 @@ int context_free() {
         dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy); dfree(l.ws.hcounts); dfree(l.ws.seg_first_h);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
-        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev);
+        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev); dfree(l.cum);
+        for (hipEvent_t& e : l.ring_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
         if (l.graph) (void)hipGraphDestroy(l.graph);
         if (l.done) (void)hipEventDestroy(l.done);
@@ -126,7 +135,7 @@ int context_free() {
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
     if (g.resolved) { (void)hipEventDestroy(g.resolved); g.resolved = nullptr; }
-    g.live = false; g.scene = nullptr; g.P = g.capacity = 0;
+    g.live = false; g.tiles = false; g.scene = nullptr; g.P = g.capacity = 0;
     return 0;
 }
 
@@ -175,38 +184,55 @@ int lane_init(Lane& l, int idx) {
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * 2 * ((size_t)g.traceDepth + 2), hipHostMallocDefault)) != hipSuccess) return (int)e;      // counts, then hcounts
-    l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
+    const Camera& cam = g.scene->state.camera;
+    if (g.tiles) {
+        // tiles in flight: lane idx renders the idx-th band of rows of EVERY iteration into the one shared plane; its paths are a contiguous
+        // range of the reference's pixel order, so its compacted slots continue those of the bands above (Workspace::cum_*)
+        l.n_parts = g.n_lanes; l.part = idx; l.tile_rows = (cam.resolution.y + g.n_lanes - 1) / g.n_lanes;
+        l.plane = g.planes;
+        l.ws.slot_bias = 0;
+        if ((rc = dalloc(&l.cum, (size_t)PTK_CUM_RING * ((size_t)g.traceDepth + 2)))) return rc;
+        if ((e = hipMemsetAsync(l.cum, 0, sizeof(int) * PTK_CUM_RING * ((size_t)g.traceDepth + 2), l.stream)) != hipSuccess) return (int)e;
+        for (hipEvent_t& ev : l.ring_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    } else {
+        l.n_parts = g.n_parts; l.part = g.part; l.tile_rows = g.tile_rows;
+        l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
+        // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
+        l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;          // fits an int: checked in context_init
+    }
+    l.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, l.n_parts, l.part, l.tile_rows);
+    l.capacity = l.n_pix * g.spp;
+    l.full_bounces = g.traceDepth;                  // until live counts of earlier iterations say otherwise (note_counts)
+    l.gen_late = 0;
     l.ws.plane_stride = g.spp > 1 ? 3u * (unsigned)g.P : 0u;      // 0: no sample-plane bits in pixelIndex (pixel_ptr, ptk_kernels.hip)
     l.ws.spp = g.spp;
-    // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
-    l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;          // fits an int: checked in context_init
-    if ((rc = alloc_paths(l.bufA, g.capacity))) return rc;
-    if ((rc = alloc_paths(l.bufB, g.capacity))) return rc;
-    if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.hits.p_mat, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.hits.uv_ids, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.hitsB.t_n, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.hitsB.p_mat, 4 * (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.hitsB.uv_ids, 4 * (size_t)g.capacity))) return rc;
-    const size_t slots = ((size_t)g.capacity + 255) / 256 * 256 + 256;          // physical slots: whole 256-slot windows
+    if ((rc = alloc_paths(l.bufA, l.capacity))) return rc;
+    if ((rc = alloc_paths(l.bufB, l.capacity))) return rc;
+    if ((rc = dalloc(&l.hits.t_n, 4 * (size_t)l.capacity))) return rc;
+    if ((rc = dalloc(&l.hits.p_mat, 4 * (size_t)l.capacity))) return rc;
+    if ((rc = dalloc(&l.hits.uv_ids, 4 * (size_t)l.capacity))) return rc;
+    if ((rc = dalloc(&l.hitsB.t_n, 4 * (size_t)l.capacity))) return rc;
+    if ((rc = dalloc(&l.hitsB.p_mat, 4 * (size_t)l.capacity))) return rc;
+    if ((rc = dalloc(&l.hitsB.uv_ids, 4 * (size_t)l.capacity))) return rc;
+    const size_t slots = ((size_t)l.capacity + 255) / 256 * 256 + 256;          // physical slots: whole 256-slot windows
     if ((rc = dalloc(&l.hrA, slots))) return rc;
     if ((rc = dalloc(&l.hrB, slots))) return rc;
     if ((rc = dalloc(&l.ws.tr_valid, slots))) return rc;
     if ((rc = dalloc(&l.ws.tr_heavy, slots))) return rc;
-    const size_t blocks = ((size_t)g.capacity + 255) / 256 + 2;
+    const size_t blocks = ((size_t)l.capacity + 255) / 256 + 2;
     if ((rc = dalloc(&l.ws.agg_h, blocks))) return rc;
     if ((rc = dalloc(&l.ws.hit_pref, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.seg_first_h, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.hcounts, (size_t)g.traceDepth + 2))) return rc;
     if ((rc = dalloc(&l.ws.agg_a, blocks))) return rc;
     if ((rc = dalloc(&l.ws.agg_b, blocks))) return rc;
-    if ((rc = dalloc(&l.ws.valid_a, (size_t)g.capacity))) return rc;
-    if ((rc = dalloc(&l.ws.valid_b, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.valid_a, (size_t)l.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.valid_b, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.ws.counts, (size_t)g.traceDepth + 2))) return rc;
     if ((rc = dalloc(&l.ws.queue, 1))) return rc;
-    if ((rc = dalloc(&l.ws.list, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.list, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
-    if ((rc = dalloc(&l.ws.srcidx, (size_t)g.capacity))) return rc;
+    if ((rc = dalloc(&l.ws.srcidx, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.ws.seg_pref, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.seg_first, blocks + 16))) return rc;
     const size_t n_done = 32 * ((size_t)blocks / 32 + 3);          // top counter + one per 32 blocks, each on its own 128-B line (segments_tail)
@@ -221,7 +247,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.wide_lpr = pick_lpr(g.n_lanes);            // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
     l.ws.segmented = (g.pipeline != 4);
-    l.ws.capacity = g.capacity;
+    l.ws.capacity = l.capacity;
     l.last_iter = 0;
     return 0;
 }
@@ -234,8 +260,6 @@ int context_init(Scene* scene) {
     g.scene = scene;
     g.P = cam.resolution.x * cam.resolution.y;
     g.traceDepth = scene->state.traceDepth;
-    g.full_bounces = g.traceDepth;                  // until live counts of earlier iterations say otherwise (note_counts)
-    g.gen_late = 0;
     g.hint_mode = -1;
     if (g.traceDepth < 1 || g.P < 1) return PTK_E_BADARG;
     g.n_pix = local_path_count(cam.resolution.x, cam.resolution.y, g.n_parts, g.part, g.tile_rows);
@@ -249,8 +273,17 @@ int context_init(Scene* scene) {
     if ((e = hipEventCreate(&g.ev0)) != hipSuccess) return (int)e;
     if ((e = hipEventCreate(&g.ev1)) != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&g.resolved, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    // tiles in flight: as many lanes as there are non-empty bands of ceil(H / K) rows; one shared radiance plane
+    g.tiles = g.want_tiles > 1;
+    if (g.tiles) {
+        if (g.n_lanes != 1 || g.n_parts != 1 || g.spp != 1) return PTK_E_BADARG;       // (not combined with iterations in flight / the multi-GPU tile partition / samples per launch)
+        if (!trace_pipeline(g.pipeline)) return PTK_E_BADARG;                           // (only the fused launches carry the bands' cumulative hit counts)
+        const int rows = (cam.resolution.y + g.want_tiles - 1) / g.want_tiles;
+        g.n_lanes = (cam.resolution.y + rows - 1) / rows;
+        if (g.n_lanes < 2) { g.tiles = false; g.n_lanes = 1; }
+    }
     const size_t plane = 3 * (size_t)g.P;
-    const size_t n_planes = (size_t)g.n_lanes * g.spp;
+    const size_t n_planes = g.tiles ? 1 : (size_t)g.n_lanes * g.spp;
     if ((rc = dalloc(&g.planes, plane * n_planes))) return rc;
     if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * n_planes)) != hipSuccess) return (int)e;
     if (n_planes > 1) { if ((rc = dalloc(&g.image, plane))) return rc; } else g.image = g.planes;
@@ -292,7 +325,7 @@ bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 4 && g.pipeline != 
 // the staged kernels are 1-3 % ahead (bunny scene 5.70 vs 5.62 Grays/s); the traversal counters are only kept by the staged kernels
 bool use_trace_pipeline() {
     if (!trace_pipeline(g.pipeline) || (g.lanes.size() && g.lanes[0].ws.stats)) return false;
-    if (g.pipeline == 10 || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline)) return true;      // (tiny mesh: walked inside the fused kernel)
+    if (g.pipeline == 10 || g.tiles || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline)) return true;      // (tiny mesh: walked inside the fused kernel; tiles in flight: only the fused launches carry the bands' cumulative hit counts)
     // larger meshes: a BVH stage follows every launch either way.  The staged kernels are ahead in BSDF / DIRECT (bunny scene 5.93 vs 5.85, 7.8 vs
     // 7.0 Grays/s); in MIS the fused kernel is, since its shadow rays run in a balanced phase at six waves per SIMD (5.69 vs 5.55)
     return current_mode() == PTK_MODE_MIS;
@@ -308,18 +341,22 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     const SceneView S = dev_view(*g.scene);
     Workspace ws = L.ws;
     ws.iter_dev = from_device_iter ? L.iter_dev : nullptr;
-    ws.iter_stride = g.n_lanes * g.n_shards;
+    ws.iter_stride = (g.tiles ? 1 : g.n_lanes) * g.n_shards;       // (tiles in flight: every lane renders every iteration)
     ws.dbg_shift0 = g_debug_slot_shift; ws.dbg_shift_deep = g_debug_slot_shift_deep;
-    ws.gen_late = g.gen_late;
-    const int full = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
+    ws.gen_late = L.gen_late;
+    if (g.tiles) {
+        const int li = (int)(&L - &g.lanes[0]);
+        ws.cum_prev = li > 0 ? g.lanes[li - 1].cum : nullptr; ws.cum_out = L.cum; ws.cum_stride = g.traceDepth + 2; ws.ring_div = g.n_shards;
+    }
+    const int full = sparse_tail() ? std::min(std::max(L.full_bounces, 1), g.traceDepth) : g.traceDepth;
     if (use_trace_pipeline()) {
         // launch 0 generates the camera rays and traces bounce 0; launch dt shades bounce dt - 1 and traces bounce dt (k_shade_trace)
         void (*mark)(int, bool) = g_prof.on ? prof_mark : no_mark;
         TraceBufs A = {L.bufA, L.hits, L.hrA}, B = {L.bufB, L.hitsB, L.hrB};
         TraceBufs *cur = &A, *nxt = &B;
-        int rc = launch_shade_trace(S, mode, true, cam, g.n_parts, g.part, g.tile_rows, g.n_pix, g.traceDepth, iter, 0, g.capacity, A, A, L.plane, ws, L.stream, false, mark);
+        int rc = launch_shade_trace(S, mode, true, cam, L.n_parts, L.part, L.tile_rows, L.n_pix, g.traceDepth, iter, 0, L.capacity, A, A, L.plane, ws, L.stream, false, mark);
         for (int dt = 1; dt <= full && !rc; ++dt) {
-            rc = launch_shade_trace(S, mode, false, cam, g.n_parts, g.part, g.tile_rows, g.n_pix, g.traceDepth, iter, dt, g.capacity, *cur, *nxt, L.plane, ws, L.stream,
+            rc = launch_shade_trace(S, mode, false, cam, L.n_parts, L.part, L.tile_rows, L.n_pix, g.traceDepth, iter, dt, L.capacity, *cur, *nxt, L.plane, ws, L.stream,
                                     dt == g.traceDepth, mark);
             std::swap(cur, nxt);
         }
@@ -331,14 +368,14 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
         return rc;
     }
     prof_mark(0, true);
-    int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, g.n_parts, g.part, g.tile_rows, g.n_pix, g.spp, ws.counts, L.stream);
+    int rc = launch_generate(cam, iter, ws.iter_dev, g.traceDepth, L.bufA, L.n_parts, L.part, L.tile_rows, L.n_pix, g.spp, ws.counts, L.stream);
     prof_mark(0, false);
     if (rc) return rc;
     PtkPaths cur = L.bufA, nxt = L.bufB;
     for (int depth = 0; depth < full; ++depth) {
         const bool last = depth == g.traceDepth - 1;      // false for every full-width bounce when k_tail follows: it steps the iteration number
-        if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
-        else rc = launch_bounce_staged(S, mode, iter, depth, g.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, last);
+        if (g_prof.on) rc = launch_bounce_staged_profiled(S, mode, iter, depth, L.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, prof_mark, last);
+        else rc = launch_bounce_staged(S, mode, iter, depth, L.capacity, cur, nxt, L.hits, L.plane, ws, L.stream, last);
         if (rc) return rc;
         PtkPaths t = cur; cur = nxt; nxt = t;
     }
@@ -365,14 +402,14 @@ void note_counts(Lane& L) {
     int d_new = g.traceDepth;
     for (int d = 1; d < g.traceDepth; ++d) if (cnt[d] <= kTailPaths) { d_new = d; break; }
     // hysteresis: widen at once, narrow only when the count is clearly below the threshold (no graph re-capture ping-pong)
-    if (d_new > g.full_bounces || (d_new < g.full_bounces && cnt[d_new] <= kTailPaths / 2)) g.full_bounces = d_new;
+    if (d_new > L.full_bounces || (d_new < L.full_bounces && cnt[d_new] <= kTailPaths / 2)) L.full_bounces = d_new;
     // camera rays that hit something / camera rays (fused pipeline, compact streams): below ~half, the camera launch stores the path state of
     // the hits only, after its trace phase (k_shade_trace, GenArgs::late_stores); hysteresis as above.  Results never depend on it.
     // (only the hit-dense launches write hcounts[]: after a SPLIT launch h0 is a stale zero and would read as "open scene" — ADVICE r3)
     const long long n0 = L.h_counts[0], h0 = L.h_counts[g.traceDepth + 2];
     if (n0 > 0 && hit_dense_pipeline()) {
-        if (!g.gen_late && 100 * h0 < 45 * n0) g.gen_late = 1;
-        else if (g.gen_late && 100 * h0 > 55 * n0) g.gen_late = 0;
+        if (!L.gen_late && 100 * h0 < 45 * n0) L.gen_late = 1;
+        else if (L.gen_late && 100 * h0 > 55 * n0) L.gen_late = 0;
     }
 }
 int request_counts(Lane& L) {
@@ -411,7 +448,7 @@ int build_graph(Lane& L, int iter, int mode) {
 
 int replay_iteration(Lane& L, int iter, int mode) {
     hipError_t e;
-    if (!L.graph_exec || L.graph_mode != mode || L.graph_full != g.full_bounces || L.graph_late != g.gen_late) {
+    if (!L.graph_exec || L.graph_mode != mode || L.graph_full != L.full_bounces || L.graph_late != L.gen_late) {
         const int rc = build_graph(L, iter, mode);
         if (rc == -1000) {
             // capture / instantiate refused by the runtime: same kernels, launched one by one (identical results)
@@ -422,7 +459,7 @@ int replay_iteration(Lane& L, int iter, int mode) {
             return enqueue_iteration(L, iter, mode, false);
         }
         if (rc) return rc;
-        L.graph_mode = mode; L.graph_full = g.full_bounces; L.graph_late = g.gen_late;
+        L.graph_mode = mode; L.graph_full = L.full_bounces; L.graph_late = L.gen_late;
         L.expected_iter = -1;
     }
     if (L.expected_iter != iter) {           // first replay, or the caller jumped in the iteration sequence
@@ -430,8 +467,26 @@ int replay_iteration(Lane& L, int iter, int mode) {
         if ((e = hipStreamSynchronize(L.stream)) != hipSuccess) return (int)e;     // &iter is a stack address
     }
     if ((e = hipGraphLaunch(L.graph_exec, L.stream)) != hipSuccess) return (int)e;
-    L.expected_iter = iter + g.n_lanes * g.n_shards;
+    L.expected_iter = iter + (g.tiles ? 1 : g.n_lanes) * g.n_shards;
     return 0;
+}
+
+static void reset_hints() { for (Lane& l : g.lanes) { l.full_bounces = g.traceDepth; l.gen_late = 0; l.counts_pending = false; l.fresh_hint = 0; } }
+
+// one iteration of one lane: replayed from its hipGraph or enqueued launch by launch
+static int lane_iteration(Lane& L, int iter, int mode) {
+    if (L.wait_resolved) {                   // lane 0 may still be summing / tone-mapping this lane's radiance for the previous pbo
+        const hipError_t e = hipStreamWaitEvent(L.stream, g.resolved, 0);
+        if (e != hipSuccess) return (int)e;
+        L.wait_resolved = false;
+    }
+    L.last_iter = iter;
+    g_prof.stream = L.stream;
+    note_counts(L);
+    int rc;
+    if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
+    else { L.expected_iter = -1; rc = enqueue_iteration(L, iter, mode, false); }
+    return rc ? rc : request_counts(L);
 }
 
 int render_iteration(unsigned char* pbo, int step) {
@@ -441,29 +496,36 @@ int render_iteration(unsigned char* pbo, int step) {
     // iteration sharding (multi-GPU validation mode): this process renders iterations shard+1, shard+1+n, ... of the
     // whole frame; lanes are assigned by call number so that every lane is used whatever n_shards is
     const int iter = (step - 1) * g.n_shards + g.shard + 1;
-    const int li = (step - 1) % g.n_lanes;
-    Lane& L = g.lanes[li];
-    g.last_lane = li;
-    L.last_iter = iter;
-    g_prof.stream = L.stream;
-    if (L.wait_resolved) {                   // lane 0 may still be summing this lane's plane for the previous pbo
-        const hipError_t e = hipStreamWaitEvent(L.stream, g.resolved, 0);
-        if (e != hipSuccess) return (int)e;
-        L.wait_resolved = false;
-    }
     const int mode = current_mode();
     if (mode != g.hint_mode) {
         // the full-width hint was learnt from another sample mode's live counts (DIRECT dies after one bounce, BSDF
         // does not): start again from "every bounce at full width" and ignore read-backs that are still in flight
-        g.full_bounces = g.traceDepth; g.gen_late = 0;
-        for (Lane& l : g.lanes) { l.counts_pending = false; l.fresh_hint = 0; }
+        reset_hints();
         g.hint_mode = mode;
     }
-    note_counts(L);
-    int rc;
-    if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
-    else { L.expected_iter = -1; rc = enqueue_iteration(L, iter, mode, false); }
-    return rc ? rc : request_counts(L);
+    if (g.tiles) {
+        // TILES IN FLIGHT.  Lane k renders band k of this iteration.  Its compacted slots — the reference's RNG keys — continue those of the
+        // bands above, so it starts the iteration when band k - 1 has FINISHED it (whose cumulative hit counts per bounce are then final,
+        // Workspace::cum_*): band k of iteration i runs beside band k - 1 of iteration i + 1, band k - 2 of i + 2, ... — a software pipeline
+        // over (band, iteration) that keeps K launches in flight like K iterations in flight do, while every pixel still receives its
+        // iterations in order: the image is the reference's own sum, bit for bit.  The counts live in a ring of PTK_CUM_RING iterations:
+        // band k - 1 may not start iteration i before band k has finished iteration i - PTK_CUM_RING (it would overwrite what band k reads).
+        const int slot = (step - 1) & (PTK_CUM_RING - 1);
+        for (int k = 0; k < g.n_lanes; ++k) {
+            Lane& L = g.lanes[k];
+            hipError_t e;
+            if (k > 0 && (e = hipStreamWaitEvent(L.stream, g.lanes[k - 1].ring_ev[slot], 0)) != hipSuccess) return (int)e;                             // band above: this iteration done
+            if (k + 1 < g.n_lanes && step > PTK_CUM_RING && (e = hipStreamWaitEvent(L.stream, g.lanes[k + 1].ring_ev[slot], 0)) != hipSuccess) return (int)e;   // band below: iteration i - RING done
+            const int rc = lane_iteration(L, iter, mode);
+            if (rc) return rc;
+            if ((e = hipEventRecord(L.ring_ev[slot], L.stream)) != hipSuccess) return (int)e;
+        }
+        g.last_lane = g.n_lanes - 1;
+        return 0;
+    }
+    const int li = (step - 1) % g.n_lanes;
+    g.last_lane = li;
+    return lane_iteration(g.lanes[li], iter, mode);
 }
 
 // all lanes' work so far -> visible to lane 0's stream (event edges only, no host wait)
@@ -480,7 +542,7 @@ int join_on_lane0() {
 int resolve_image() {
     int rc = join_on_lane0();
     if (rc) return rc;
-    if (g.n_lanes * g.spp > 1) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
+    if (!g.tiles && g.n_lanes * g.spp > 1) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
     if (rc || g.n_lanes == 1) return rc;
     // the other lanes' next iterations write the planes this sum reads: they wait for it (event edge, no host wait)
     const hipError_t e = hipEventRecord(g.resolved, g.lanes[0].stream);
@@ -516,6 +578,15 @@ int ptk_pathtrace(unsigned char* pbo, int frame, int iter) {
 int ptk_set_sample_mode(int mode) { if (mode < 0 || mode > 2) return PTK_E_BADARG; g_mode_override = mode; return 0; }
 int ptk_get_sample_mode(void) { return current_mode(); }
 
+/* Tiles in flight (1..16, default 1 = off; set before ptk_pathtrace_init; not combined with iterations in flight, the tile partition or
+ * samples per launch): every iteration is rendered as K bands of rows on K streams, band k of iteration i beside band k - 1 of iteration
+ * i + 1 (render_iteration).  Unlike iterations in flight this keeps the reference's accumulation order: the image is bit-identical to
+ * the default's. */
+int ptk_set_tiles_in_flight(int tiles) {
+    if (tiles < 1 || tiles > kMaxLanes || g.live) return PTK_E_BADARG;
+    g.want_tiles = tiles;
+    return 0;
+}
 int ptk_set_iterations_in_flight(int lanes) {
     if (lanes < 1 || lanes > kMaxLanes || g.live) return PTK_E_BADARG;     // set before ptk_pathtrace_init
     g.n_lanes = lanes;
@@ -571,6 +642,18 @@ int ptk_copy_image_to_device(float* dst) {
 int ptk_get_live_counts(int* counts, int* traced_depth) {          // of the LAST ptk_pathtrace call
     if (!g.live) return PTK_E_NOSCENE;
     if (!counts) return PTK_E_BADARG;
+    if (g.tiles) {                                                  // the bands of the last iteration together
+        std::vector<int> part((size_t)g.traceDepth + 1);
+        for (int d = 0; d <= g.traceDepth; ++d) counts[d] = 0;
+        for (Lane& l : g.lanes) {
+            hipError_t e = hipMemcpyAsync(part.data(), l.ws.counts, sizeof(int) * part.size(), hipMemcpyDeviceToHost, l.stream);
+            if (e != hipSuccess) return (int)e;
+            if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) return (int)e;
+            for (int d = 0; d <= g.traceDepth; ++d) counts[d] += part[d];
+        }
+        if (traced_depth) { int d = 0; while (d < g.traceDepth && counts[d] > 0) ++d; *traced_depth = d; }
+        return 0;
+    }
     Lane& L = g.lanes[g.last_lane];
     hipError_t e = hipMemcpyAsync(counts, L.ws.counts, sizeof(int) * ((size_t)g.traceDepth + 1), hipMemcpyDeviceToHost, L.stream);
     if (e != hipSuccess) return (int)e;
@@ -616,7 +699,7 @@ int ptk_set_iteration_sharding(int n_shards, int shard) {
 int ptk_get_open_scene_hint(int* out) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!out) return PTK_E_BADARG;
-    *out = g.gen_late;
+    *out = g.lanes[0].gen_late;
     return 0;
 }
 /* Bounces the render loop currently enqueues at full width (the rest of an iteration runs in the single-workgroup k_tail);
@@ -624,7 +707,9 @@ int ptk_get_open_scene_hint(int* out) {
 int ptk_get_full_width_bounces(int* out) {
     if (!g.live) return PTK_E_NOSCENE;
     if (!out) return PTK_E_BADARG;
-    *out = sparse_tail() ? std::min(std::max(g.full_bounces, 1), g.traceDepth) : g.traceDepth;
+    int fb = 0;
+    for (const Lane& l : g.lanes) fb = std::max(fb, l.full_bounces);
+    *out = sparse_tail() ? std::min(std::max(fb, 1), g.traceDepth) : g.traceDepth;
     return 0;
 }
 #ifdef PTK_TEST_HOOKS
@@ -636,20 +721,20 @@ int ptk_debug_slot_shift(int k0, int k1) { g_debug_slot_shift = k0; g_debug_slot
 int ptk_debug_clear_image(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();
-    const int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (size_t)g.n_lanes * g.spp));
+    const int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp)));
     return rc ? rc : rc_of(hipDeviceSynchronize());      // null-stream clear vs the lanes' non-blocking streams
 }
 #endif
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
+    if (g.live && g.tiles && !trace_pipeline(which)) return PTK_E_BADARG;
     g.pipeline = which;
     for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = pick_lpr(g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
     invalidate_graphs();
     // the hints were learnt from the other pipeline's counters (hcounts[] is only written by the hit-dense launches): start again, like a
     // sample-mode switch does
-    g.full_bounces = g.traceDepth; g.gen_late = 0;
-    for (Lane& l : g.lanes) { l.counts_pending = false; l.fresh_hint = 0; }
+    reset_hints();
     return 0;
 }
 /* Per-kernel timing: begin -> every launch of the following ptk_pathtrace calls is bracketed by HIP events on the
@@ -678,6 +763,7 @@ int ptk_profile_end(float* ms4, int* launches4) {
 /* Enable (1) / disable (0) the BVH traversal counters; read them with ptk_get_traversal_stats (node visits, triangle tests). */
 int ptk_enable_traversal_stats(int on) {
     if (!g.live) return PTK_E_NOSCENE;
+    if (on && g.tiles) return PTK_E_BADARG;              // (the counters live in the staged kernels, which tiles in flight cannot use)
     sync_all();
     for (Lane& l : g.lanes) {
         if (on && !l.ws.stats) {

@@ -15,6 +15,7 @@ namespace ptk {
 // BVH walk of the work-list rays (both give bit-identical hits): the reference's threaded walk, one ray per lane (fewest
 // instructions, longest dependent chain); four lanes per ray over the 8-wide collapsed tree (default).
 enum { PTK_WALK_AUTO = 0, PTK_WALK_THREADED = 1, PTK_WALK_WIDE = 2 };
+enum { PTK_CUM_RING = 4 };       // iterations a band may run ahead of the band below it (tiles in flight), power of two
 
 void set_light_fix(bool on);            // opt-in fixed cube lights (ptk_set_light_fix)
 bool light_fix_enabled();
@@ -69,6 +70,10 @@ struct Workspace {               // per-render-context scratch, device memory
     int gen_late = 0;            // host hint (pathtrace.hip: note_counts): the camera launch stores the hits' path state only, after its trace phase
     int* hcounts = nullptr;      // fused pipeline, compact streams: hcounts[d] = paths of bounce d that hit something [depth + 2]
     int* seg_first_h = nullptr;  // ... and the window of hit index 256 B [blocks + 16]
+    // tiles in flight (ptk_set_tiles_in_flight, pathtrace.hip): this lane renders one band of pixel rows; its compacted slots continue those of
+    // the bands above it.  cum_*[ring][d] = paths of bounce d that hit something in this band and all bands above it, ring = iteration mod
+    // PTK_CUM_RING (the band above runs ahead); cum_prev = the band above's table (null for the first band), cum_out = this band's; null = off
+    const int* cum_prev = nullptr; int* cum_out = nullptr; int cum_stride = 0, ring_div = 1;
     int wide_lpr = 4;            // lanes per ray of the wide walk (4 or 2; ptk_kernels.hip k_traverse_wide)
     int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)
     int capacity = 0;

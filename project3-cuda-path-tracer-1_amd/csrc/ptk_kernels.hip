@@ -71,6 +71,12 @@ __device__ __forceinline__ int block_excl_prefix(int flag, int& total) {
     return off + within;
 }
 
+// Tiles in flight: the compacted slot of a hit path = its rank among the hits of ITS band + the hits of the same bounce in all bands above
+// (a band is a contiguous range of the reference's pixel order, and stable compaction keeps it contiguous at every bounce).  The band above has
+// finished this iteration before this one starts it (pathtrace.hip), so its cumulative counts are final; `row` = this iteration's ring slot.
+__device__ __forceinline__ int cum_row(int step, int ring_div, int cum_stride) { return (((step - 1) / ring_div) & (PTK_CUM_RING - 1)) * cum_stride; }
+__device__ __forceinline__ int cum_read(const int* cum_prev, int row, int d) { return cum_prev ? cum_prev[row + d] : 0; }
+
 // sum of agg[0 .. b): every block reduces its predecessors' aggregates itself (<= 10 loads/thread at 800x800)
 __device__ __forceinline__ int prior_blocks(const int* __restrict__ agg, int b) {
     __shared__ int red[PTK_WAVES];
@@ -802,11 +808,16 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, 
 // PTK_VALID_TRI; writes the hit rank of every slot (hr: >= 0 rank among the hits of its window, -1 miss, -2 empty) and the window's
 // hit count, from which its last block builds hit_pref (a triangle hit changes the ranks the shading keys are made of).
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits, const int* __restrict__ valid,
-                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref) {
+                                                          int* __restrict__ hr, int* __restrict__ agg_h, int* __restrict__ done, int* __restrict__ hit_pref,
+                                                          const int* __restrict__ cum_prev, int* __restrict__ cum_out, int cum_stride, int ring_div, int cum_d,
+                                                          int iter_arg, const int* __restrict__ iter_ptr) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
+    // tiles in flight (cum_out != null): the hits of the traced bounce cum_d in this band and the bands above, final only here
+    const int cum_at = cum_out ? cum_row(iter_ptr ? *iter_ptr : iter_arg, ring_div, cum_stride) + cum_d : 0;
     if (b * PTK_BLOCK >= n) {
         if (n <= 0 && b == 0 && threadIdx.x < 8) hit_pref[threadIdx.x] = 0;
+        if (n <= 0 && b == 0 && threadIdx.x == 0 && cum_out) cum_out[cum_at] = cum_read(cum_prev, 0, cum_at);
         return;
     }
     const int i = b * PTK_BLOCK + threadIdx.x;
@@ -840,7 +851,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
     __syncthreads();
     if (!s_last) return;
     for (int k = threadIdx.x; k <= ng; k += PTK_BLOCK) __hip_atomic_store(done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)prefix_block<PTK_BLOCK, true>(nb, agg_h, hit_pref);
+    const int total_h = prefix_block<PTK_BLOCK, true>(nb, agg_h, hit_pref);
+    if (threadIdx.x == 0 && cum_out) cum_out[cum_at] = cum_read(cum_prev, 0, cum_at) + total_h;
 }
 // environment map on a miss, fused pipeline: slot g of the traced stream missed iff the top bits of hr[g] are 10 (00: hit, 11: empty slot)
 __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths, const int* __restrict__ hr,
@@ -1298,7 +1310,8 @@ struct TraceIO {
     int* heavy_flag; int* heavy_agg;     // SPLIT: rays that enter the BVH root box
 };
 struct SegTail2 { int* done; int* pref; int* first; int* hit_pref; int* count_out; int* iter_advance; int iter_stride; unsigned long long* ray_total;
-                  int* first_h; int* hcount_out; };      // COMPACT (hit-dense shading): window of hit index 256 B, total hits of the launch
+                  int* first_h; int* hcount_out;       // COMPACT (hit-dense shading): window of hit index 256 B, total hits of the launch
+                  const int* cum_prev; int* cum_out; int cum_stride, ring_div; };      // tiles in flight (Workspace::cum_*), null = off
 struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix, late_stores; };
 
 // segments_block for the fused launches: the window prefix of the survivor counts (pref / first / next live count) AND the prefix of the hit
@@ -1307,7 +1320,8 @@ struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix
 template <int NT>
 __device__ __forceinline__ void segments_block2(int n_prev, const int* __restrict__ agg_s, const int* __restrict__ agg_h, int* __restrict__ pref, int* __restrict__ first,
                                                 int* __restrict__ hit_pref, int* __restrict__ count_out, int* iter_advance, int iter_stride,
-                                                int* __restrict__ first_h = nullptr, int* __restrict__ hcount_out = nullptr) {
+                                                int* __restrict__ first_h = nullptr, int* __restrict__ hcount_out = nullptr,
+                                                const int* __restrict__ cum_prev = nullptr, int* __restrict__ cum_out = nullptr, int cum_at = 0) {
     constexpr int NW = NT / 64;
     __shared__ int s_ws[NW], s_wh[NW];
     __shared__ int s_carry_s, s_carry_h;
@@ -1357,13 +1371,14 @@ __device__ __forceinline__ void segments_block2(int n_prev, const int* __restric
     if (tid == 0) {
         if (count_out) *count_out = total;
         if (hcount_out) *hcount_out = total_h;
+        if (cum_out && agg_h) cum_out[cum_at] = cum_read(cum_prev, 0, cum_at) + total_h;      // (SPLIT: k_finalize2 writes it, the hits are final there)
         if (iter_advance) *iter_advance += iter_stride;
     }
 }
 
 // end of a k_shade_trace block: publish the window's survivor and hit counts; the last block of the launch builds the tables
 template <int NT>
-__device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, int survivors, int hits, int* __restrict__ agg_s, int* __restrict__ agg_h) {
+__device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, int survivors, int hits, int* __restrict__ agg_s, int* __restrict__ agg_h, int cum_at) {
     __shared__ int s_last;
     const int nb = (n + NT - 1) / NT, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
     if (threadIdx.x == 0) {
@@ -1381,7 +1396,7 @@ __device__ __forceinline__ void segments_tail2(const SegTail2& T, int n, int b, 
     if (!s_last) return;
     for (int k = threadIdx.x; k <= ng; k += NT) __hip_atomic_store(T.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     segments_block2<NT>(n, agg_s, (T.hit_pref && agg_h) ? agg_h : nullptr, T.pref, T.first, T.hit_pref, T.count_out, T.iter_advance, T.iter_stride,
-                        (T.hit_pref && agg_h) ? T.first_h : nullptr, (T.hit_pref && agg_h) ? T.hcount_out : nullptr);
+                        (T.hit_pref && agg_h) ? T.first_h : nullptr, (T.hit_pref && agg_h) ? T.hcount_out : nullptr, T.cum_prev, T.cum_out, cum_at);
     if (threadIdx.x == 0 && T.ray_total) atomicAdd(T.ray_total, (unsigned long long)*T.count_out);     // rays of the bounce just traced
 }
 
@@ -1463,6 +1478,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         if (n <= 0 && blockIdx.x == 0) {
             if (tail.hit_pref && tid < 8) tail.hit_pref[tid] = 0;
             if (tail.hcount_out && tid == 0) *tail.hcount_out = 0;
+            if (tail.cum_out && tid == 0) { const int at = cum_row(step, tail.ring_div, tail.cum_stride) + depth + 1; tail.cum_out[at] = cum_read(tail.cum_prev, 0, at); }
             segments_block<NT, false>(0, io.agg_s, tail.pref, tail.first, tail.count_out, tail.iter_advance, tail.iter_stride);
         }
         return;
@@ -1521,6 +1537,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     } else {
         // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
         const int iter = (step - 1) * spp + 1;
+        const int slot_off = slot_bias + cum_read(tail.cum_prev, cum_row(step, tail.ring_div, tail.cum_stride), depth);      // tiles in flight: the hits of this bounce in the bands above
         const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
         // windows of the stream being read = ceil(paths the previous launch shaded / 256); the camera launch's stream (depth 0) is dense
         const int nw_prev = depth > 0 ? (d_n[-1] + NT - 1) / NT : (gen.n_pix * spp + NT - 1) / NT;
@@ -1542,7 +1559,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 const int at = (w0 + k) * NT + (i - base);
                 const int word = (COMPACT ? __float_as_int(io.hcur.t_n[4 * (size_t)at + 3]) : io.hr_cur[at]) & 0x3fffffff;      // in the normal's spare word / the hr word
                 src_mine = (w0 + k) * NT + (word & 0xff);
-                flag = 1; key = word >> 8; slot_mine = i + slot_bias;
+                flag = 1; key = word >> 8; slot_mine = i + slot_off;
             }
         } else {
             int hit_base = 0;
@@ -1553,7 +1570,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             flag = hr_word >= 0;
             // (SPLIT: k_finalize2 writes the word — a triangle hit's material is only known there)
             if (flag) key = hr_word >> 8;
-            slot_mine = hit_base + (hr_word & 0xff) + slot_bias;
+            slot_mine = hit_base + (hr_word & 0xff) + slot_off;
         }
         s_src[tid] = src_mine;
         unsigned long long bal[NKEY];
@@ -1762,7 +1779,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     } else if (!COMPACT) {
         io.hr_nxt[b * NT + tid] = -2;
     }
-    segments_tail2<NT>(tail, n, b, total, hits, io.agg_s, SPLIT ? nullptr : io.agg_h);
+    segments_tail2<NT>(tail, n, b, total, hits, io.agg_s, SPLIT ? nullptr : io.agg_h, cum_row(step, tail.ring_div, tail.cum_stride) + depth + 1);
     }
 }
 
@@ -1848,6 +1865,7 @@ struct TailArgs {
     // (hit prefix + first_h + the inverse-map words), never its misses — and takes over as soon as a bounce has few HITS, however many rays
     int hit_dense; const int* hit_pref; const int* first_h; const int* nhits;
     int* hcounts;                            // (may be null) hcounts[d] = hits of bounce d, kept up to date for the host's hand-over hint
+    const int* cum_prev; int* cum_out; int cum_stride, ring_div;      // tiles in flight (Workspace::cum_*), null = off
 };
 
 template <int MODE>
@@ -1862,9 +1880,11 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
     PtkPaths cur = A.cur, nxt = A.nxt;
     Gather G = A.G;
     int n = A.hit_dense ? *A.nhits : A.counts[A.depth0];        // paths to look at in the first bounce: its hits (hit-dense) or its live paths
+    const int crow = cum_row(step, A.ring_div, A.cum_stride);
     for (int depth = A.depth0; depth < A.trace_depth; ++depth) {
         if (n <= 0) {                                            // nothing left: the remaining bounces are empty
             for (int d = depth + 1 + threadIdx.x; d <= A.trace_depth; d += NT) A.counts[d] = 0;
+            if (A.cum_out) for (int d = depth + threadIdx.x; d <= A.trace_depth; d += NT) if (!(A.have_hits && d == A.depth0)) A.cum_out[crow + d] = cum_read(A.cum_prev, crow, d);
             if (A.hcounts) for (int d = depth + threadIdx.x; d <= A.trace_depth; d += NT) if (!(A.have_hits && d == A.depth0)) A.hcounts[d] = 0;
             break;
         }
@@ -1926,7 +1946,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
             }
             int total;
             const int local = block_excl_prefix_n<NT>(flag, total);
-            if (flag) alive = shade_path<MODE>(S, gs, mt, iter, hits_before + local + A.slot_bias + (depth >= 1 ? A.dbg_shift_deep : A.dbg_shift0), depth, h, p, img);
+            if (flag) alive = shade_path<MODE>(S, gs, mt, iter, hits_before + local + A.slot_bias + cum_read(A.cum_prev, crow, depth) + (depth >= 1 ? A.dbg_shift_deep : A.dbg_shift0), depth, h, p, img);
             int total2;
             const int local2 = block_excl_prefix_n<NT>(alive, total2);
             if (alive) {
@@ -1940,6 +1960,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
         if (threadIdx.x == 0) {
             A.counts[depth + 1] = survivors;
             if (A.hcounts && !(A.have_hits && depth == A.depth0)) A.hcounts[depth] = hits_before;      // (the traced bounce's count was written by its launch)
+            if (A.cum_out && !(A.have_hits && depth == A.depth0)) A.cum_out[crow + depth] = cum_read(A.cum_prev, crow, depth) + hits_before;
             if (A.ray_total && !(A.have_hits && depth == A.depth0)) atomicAdd(A.ray_total, (unsigned long long)n);     // (counted by the launch that traced it)
         }
         __syncthreads();                                         // this bounce's stores are visible to the whole workgroup before the next bounce reads them
@@ -2284,7 +2305,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     // layout but SPLIT): it shades the hcounts[dt - 1] paths of bounce dt - 1 that hit something, and writes hcounts[dt] = the hits it found
     const int* d_n = gen ? nullptr : (!split ? ws.hcounts : ws.counts) + (dt - 1);
     const SegTail2 tail = {ws.seg_done, ws.seg_pref, ws.seg_first, split ? nullptr : ws.hit_pref, ws.counts + dt, last ? ws.iter_dev : nullptr, ws.iter_stride, ws.ray_total,
-                           !split ? ws.seg_first_h : nullptr, !split ? ws.hcounts + dt : nullptr};
+                           !split ? ws.seg_first_h : nullptr, !split ? ws.hcounts + dt : nullptr, ws.cum_prev, ws.cum_out, ws.cum_stride, ws.ring_div};
     const int depth = dt - 1;           // RNG key depth of the bounce being shaded
     const int sbias = ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0);
     mark(gen ? 0 : 2, true);
@@ -2315,7 +2336,8 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
         else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
-        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref);
+        k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref,
+                                             ws.cum_prev, ws.cum_out, ws.cum_stride, ws.ring_div, dt, iter, ws.iter_dev);
         mark(1, false);
         if ((rc = launch_rc())) return rc;
     }
@@ -2341,6 +2363,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     A.nshaded = (depth0 > 0 ? (hit_dense ? ws.hcounts : ws.counts) + (depth0 - 1) : ws.counts);
     A.hit_dense = (hit_dense && depth0 > 0) ? 1 : 0; A.hit_pref = ws.hit_pref; A.first_h = ws.seg_first_h; A.nhits = ws.hcounts ? ws.hcounts + depth0 : nullptr;
     A.hcounts = ws.hcounts;
+    A.cum_prev = ws.cum_prev; A.cum_out = ws.cum_out; A.cum_stride = ws.cum_stride; A.ring_div = ws.ring_div;
     const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
     A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias; A.dbg_shift0 = ws.dbg_shift0; A.dbg_shift_deep = ws.dbg_shift_deep;

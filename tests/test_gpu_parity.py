@@ -552,6 +552,83 @@ def test_iterations_in_flight(ptk, orc, torch_cuda, name, res, depth, mode, lane
     assert np.array_equal(img, ref)
 
 
+TILE_CASES = [  # scene, res, depth, mode, tiles, graph replay
+    ("cornell.txt", (128, 96), 6, "BSDF", 3, False),
+    ("cornell.txt", (128, 100), 6, "MIS", 4, True),           # ragged last band (100 rows / 4 bands of 25)
+    ("cornell.txt", (96, 97), 3, "DIRECT", 5, True),          # 97 rows: bands of 20, the last one 17
+    ("mis_test.txt", (192, 192), 8, "MIS", 3, True),          # open scene: late camera stores, k_tail with band offsets
+    ("mis_test.txt", (128, 128), 8, "BSDF", 2, False),
+    ("metallic_analytic.txt", (128, 128), 8, "MIS", 3, True),
+    ("bunny_cornell.txt", (96, 96), 5, "BSDF", 3, True),      # SPLIT launches + BVH stage: k_finalize2 carries the bands' hit counts
+    ("bunny_cornell.txt", (64, 64), 8, "MIS", 2, False),
+    ("obj_test.txt", (96, 96), 4, "MIS", 3, True),            # tiny mesh walked inside the fused kernel (full-width streams)
+    ("textureEnv_test.txt", (128, 128), 6, "BSDF", 4, True),  # textures + ENV map
+    ("cornell.txt", (64, 16), 4, "BSDF", 16, True),           # one row per band
+]
+
+
+@pytest.mark.parametrize("name,res,depth,mode,tiles,graph", TILE_CASES)
+def test_tiles_in_flight(ptk, orc, torch_cuda, name, res, depth, mode, tiles, graph):
+    """K bands of pixel rows in flight (ptk_set_tiles_in_flight): band k of iteration i runs beside band k - 1 of iteration i + 1, every band's
+    compacted slots continue those of the bands above — so, unlike iterations in flight, the result is the DEFAULT's and the oracle's bit
+    for bit: same RNG keys (pathtrace.cu:458,532), same accumulation order per pixel (pathtrace.cu:697-810).  11 iterations: the ring of
+    per-band hit counts (PTK_CUM_RING = 4 iterations) wraps twice."""
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, tiles=tiles, graph=graph)
+    ref = np.zeros((o.P, 3), np.float32)
+    rays = 0
+    for it in range(1, 12):
+        r.iterate(it)
+        rr, live = o.pathtrace(m, it, ref); rays += rr
+        if it in (1, 2, 6, 11):
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, live), (it, counts, live)
+    img = r.image()
+    assert r.ray_total() == rays
+    r.close()
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+
+
+def test_tiles_in_flight_full_size(ptk, orc, torch_cuda):
+    """the benchmarked scene at its own size (cornell.txt 800 x 800 depth 8, BSDF): 3 bands in flight + graph replay == one iteration at a
+    time == the oracle"""
+    s = ptk.Scene(os.path.join(SC, "cornell.txt"))
+    r = ptk.Renderer(s, ptk.MODE_BSDF, tiles=3, graph=True)
+    for it in range(1, 7):
+        r.iterate(it)
+    img = r.image(); counts, _ = r.live_counts(); r.close()
+    r = ptk.Renderer(s, ptk.MODE_BSDF)
+    for it in range(1, 7):
+        r.iterate(it)
+    img0 = r.image(); counts0, _ = r.live_counts(); r.close()
+    assert np.array_equal(counts, counts0) and np.array_equal(img, img0)
+    orc.set_threads(host_threads())
+    try:
+        o = orc.Scene(os.path.join(SC, "cornell.txt"))
+        ref = np.zeros((o.P, 3), np.float32)
+        for it in range(1, 7):
+            o.pathtrace(orc.MODE_BSDF, it, ref)
+    finally:
+        orc.set_threads(1)
+    assert np.array_equal(img, ref)
+
+
+def test_tiles_in_flight_refuses_what_it_cannot_do(ptk, torch_cuda):
+    s = ptk.Scene(os.path.join(SC, "cornell.txt"), res=(64, 64), depth=3)
+    for kw in (dict(tiles=2, in_flight=2), dict(tiles=2, partition=(2, 0, 8)), dict(tiles=2, spp=2), dict(tiles=2, pipeline=8)):
+        with pytest.raises(ptk.PtkError):
+            ptk.Renderer(s, ptk.MODE_BSDF, **kw)
+        ptk.lib.ptk_pathtrace_free()
+        for fn, a in ((ptk.lib.ptk_set_iterations_in_flight, (1,)), (ptk.lib.ptk_set_tiles_in_flight, (1,)), (ptk.lib.ptk_set_tile_partition, (1, 0, 1)),
+                      (ptk.lib.ptk_set_samples_per_launch, (1,)), (ptk.lib.ptk_set_pipeline, (0,))):
+            assert fn(*a) == 0
+    r = ptk.Renderer(s, ptk.MODE_BSDF, tiles=2)
+    assert ptk.lib.ptk_set_pipeline(8) == ptk.E_BADARG and ptk.lib.ptk_enable_traversal_stats(1) == ptk.E_BADARG
+    r.iterate(1); r.close()
+
+
 @pytest.mark.parametrize("name,res,depth,mode,spp,part,lanes", [
     ("cornell.txt", (96, 64), 5, "MIS", 4, (1, 0, 1), 1),
     ("cornell.txt", (96, 80), 4, "BSDF", 2, (2, 1, 8), 1),          # the multi-GPU configuration: tiles x samples
