@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--bvh-scene", default="bunny_cornell.txt", help="second roofline measurement on a BVH scene ('' = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="ptk_set_pipeline value (A/B comparisons)")
+    ap.add_argument("--tiles", type=int, default=0, help="> 1: the headline run uses K tiles in flight (ptk_set_tiles_in_flight; bit-identical to one iteration at a time) instead of iterations in flight")
+    ap.add_argument("--collective", default="auto", choices=["auto", "reduce", "gather"],
+                    help="N > 1, tile sharding: how the radiance reaches rank 0 — SUM-reduce of the full frame, or gather of the owned row tiles (1/N of the bytes); "
+                         "auto = reduce unless it costs more than 2 %% of a step")
     ap.add_argument("--lean", type=int, default=0, help="1: only the headline run and the roofline pass (no reference_order / cpu_baseline / BVH scene / contracted child)")
     return ap.parse_args()
 
@@ -166,8 +170,9 @@ def measure_kernels(ptk, scene, mode, pipeline, steps):
     return prof, rays, counts, nodes, tris, rays_s
 
 
-ROUND = "r3"
+ROUND = "r4" if os.path.exists(os.path.join(ROOT, "profiles", "r4_pmc.json")) else "r3"      # the committed profile set the line cites
 PMC_FILE = "profiles/%s_pmc.json" % ROUND
+PMC_TIMED_FILE = "profiles/%s_pmc_timed.json" % ROUND
 BYTES_PER_PATH_BOUNCE = 224   # whole bounce (intersect 76 + 2 x 8 index-only compaction + shade 132) per path-bounce
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4      # wave-instructions / s: 1024 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz
 
@@ -184,18 +189,20 @@ def pmc_record(scene_file):
 
 def rocprof_avg_us(scene_file, kernel_substr):
     """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summaries of the single-stream configuration
-    (profiles/r3_<scene>_kernel_stats_inflight1_p<pipeline>.csv, produced by tools/refresh_profiles.sh with `bench.py --in-flight 1
-    --graph 0 --pipeline 0 | 8`: the fused default and the staged kernels)"""
+    (profiles/<round>_<scene>_kernel_stats_inflight1_p<pipeline>.csv, produced by tools/refresh_profiles.sh with `bench.py --in-flight 1
+    --graph 0 --pipeline 0 | 8`: the fused default and the staged kernels); where both summaries hold the kernel, the one with the most
+    calls (VERDICT r3 #7: the 40-call sample of the profiling pass used to shadow the 8 744-call one)"""
     import csv
+    best = None
     for p in (0, 8):
         try:
             f = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats_inflight1_p%d.csv" % (ROUND, (scene_file or "").replace(".txt", ""), p))
             for row in csv.DictReader(open(f)):
-                if kernel_substr in row["Name"]:
-                    return float(row["AverageNs"]) / 1e3
+                if kernel_substr in row["Name"] and (best is None or int(row["Calls"]) > best[0]):
+                    best = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
         except Exception:
             pass
-    return None
+    return best[1] if best else None
 
 
 def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_file=None):
@@ -217,7 +224,7 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
                       "~0.2 of 8 TB/s because it needs ~14 VALU instructions per byte; see roofline_valu and DESIGN.md section 5",
         "kernel": "k_intersect (the staged pipeline 8's intersection kernel, the kernel SURVEY 8d's 76 B/ray is defined on)" + (" + k_list + k_traverse_wide + k_finalize (the intersect stage)" if has_bvh else ""),
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_measured": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None, "traffic": traffic,
         "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE, **hbm,
         "counters": (pmc or {}).get("counters"),
         **({"avg_launch_us_rocprof": round(rp_us, 2), "frac_rocprof": round(bytes_per_ray * rays_p / (steps * live_launches) / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
@@ -268,6 +275,10 @@ def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic_bytes_per_launch"),
             "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE,
             "frac_rocprof": round(alg_per_launch / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp else None,
+            # `frac` prices the launch at the reference's struct sizes (224 B per path-bounce); the compact streams move less.  The same launch
+            # time against the HBM bytes the counters saw = what the HBM really carries
+            "frac_measured": round(pm["traffic_bytes_per_launch"] / ((rp or avg_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if pm.get("traffic_bytes_per_launch") else None,
+            "frac_measured_note": "PMC traffic per launch / (rocprofv3 average launch time, else this run's) / 8 TB/s",
             "rocprof_note": "the same algorithmic bytes over k_shade_trace's average duration in the committed rocprofv3 summary of the single-stream configuration",
             "algorithmic_bytes_per_launch": round(rays_p * BYTES_PER_PATH_BOUNCE / launches), "bytes_per_path_bounce": BYTES_PER_PATH_BOUNCE,
             "rays_per_launch": round(rays_p / launches, 1), "avg_launch_us": round(avg_us, 2), "avg_launch_us_rocprof": round(rp, 2) if rp else None,
@@ -288,7 +299,7 @@ def roofline_valu(scene_file, roof):
     return {"achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
             "insts_valu_per_launch": c["SQ_INSTS_VALU"], "kernel": roof.get("kernel"),
             "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the pipeline's instructions "
-                    "fill the issue slots (valu_busy_estimate ~ 1.0).  Packed instructions counted once; what an instruction really costs: profiles/r3_issue_cost.txt"}
+                    "fill the issue slots (valu_busy_timed, from counters of the timed configuration).  Peak = 1024 SIMDs x 2.4 GHz nominal / 4; packed instructions counted once; what an instruction really costs: profiles/r3_issue_cost.txt"}
 
 
 def main():
@@ -305,6 +316,9 @@ def main():
     N = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if N > 1 and a.backend == "nccl" and torch.cuda.device_count() < N:
+        # RCCL needs one device per rank; sharing a card is only possible with the gloo rehearsal backend (fail fast, one clear line)
+        raise SystemExit(f"bench.py --gpus {N} --backend nccl needs {N} visible GPUs, this node shows {torch.cuda.device_count()} (use --backend gloo for a one-GPU rehearsal)")
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -328,7 +342,10 @@ def main():
         renderer-side figures."""
         weak = scaling == "weak"
         if N == 1:
-            r = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph))
+            if a.tiles > 1:
+                r = ptk.Renderer(scene, mode, pipeline=a.pipeline, tiles=a.tiles, graph=bool(a.graph))
+            else:
+                r = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph))
             calls, spp = a.steps * IPS, 1
         elif shard == "tiles":
             spp = N if weak else 1
@@ -344,9 +361,29 @@ def main():
             if N > 1:
                 dist.barrier()
 
-        def reduce_radiance():
-            """the job's one collective: SUM-reduce of the full-frame float32 radiance buffer to rank 0"""
+        own = None
+        if N > 1 and shard == "tiles":
+            # pixels of this rank's row tiles, padded to the largest rank's count (ragged last tile): what a gather moves instead of the full frame
+            counts_px = [len(ptk.partition_pixels(scene.width, scene.height, N, q, a.tile_rows).ravel()) for q in range(N)]
+            mine = torch.from_numpy(ptk.partition_pixels(scene.width, scene.height, N, rank, a.tile_rows).ravel().astype("int64")).to(red.device)
+            own = {"idx": mine, "n": counts_px, "pad": max(counts_px)}
+
+        def reduce_radiance(how="reduce"):
+            """the job's one collective.  "reduce": SUM-reduce of the full-frame float32 radiance buffer to rank 0 (zeros outside the own tiles).
+            "gather" (tile sharding only): every rank sends the pixels of its own row tiles — 1/N of the bytes — and rank 0 places them."""
             r.image_to(red)
+            if how == "gather" and own is not None:
+                part = torch.zeros((own["pad"], 3), dtype=torch.float32, device=red.device)
+                part[:len(own["idx"])] = red.index_select(0, own["idx"])
+                if a.backend != "nccl":
+                    part = part.cpu()
+                bufs = [torch.zeros_like(part) for _ in range(N)] if rank == 0 else None
+                dist.gather(part, bufs, dst=0)
+                if rank == 0:
+                    for q in range(1, N):
+                        iq = torch.from_numpy(ptk.partition_pixels(scene.width, scene.height, N, q, a.tile_rows).ravel().astype("int64")).to(red.device)
+                        red.index_copy_(0, iq, bufs[q][:own["n"][q]].to(red.device))
+                return
             if a.backend == "nccl":
                 dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
             else:                                  # rehearsal backends: stage through the host
@@ -355,8 +392,22 @@ def main():
         it = 0
         for _ in range(a.warmup * IPS):
             it += 1; r.iterate(it)
-        if N > 1:                      # warm the communicator outside the timed region
-            reduce_radiance()
+        how = "reduce"
+        t_red = t_gat = 0.0
+        if N > 1:                      # warm the communicator outside the timed region, and time both collectives alone
+            for kind in (("reduce", "gather") if own is not None else ("reduce",)):
+                reduce_radiance(kind); barrier()
+                tt0 = time.perf_counter()
+                for _ in range(3):
+                    reduce_radiance(kind)
+                barrier()
+                tt = (time.perf_counter() - tt0) / 3
+                if kind == "reduce": t_red = tt
+                else: t_gat = tt
+            if own is not None and (a.collective == "gather" or (a.collective == "auto" and t_gat < t_red)):
+                how = "gather"             # (the 2 % rule is applied below, once the step time is known: here the cheaper one is simply pre-selected)
+            if a.collective == "reduce":
+                how = "reduce"
         barrier()
         rays0 = r.ray_total()
         barrier()
@@ -366,24 +417,21 @@ def main():
             it += 1; r.iterate(it)
         dev_ms = r.timer_stop()
         if N > 1:
-            reduce_radiance()
+            # "auto": the full-frame reduce stays unless it is worth more than 2 % of the step it ends; every rank decides alike (MAX below)
+            if a.collective == "auto" and own is not None:
+                tl = torch.tensor([t_red, t_gat], dtype=torch.float64, device=cdev); dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+                how = "gather" if (float(tl[0]) > 0.02 * (time.perf_counter() - t0) / max(a.steps, 1) and float(tl[1]) < float(tl[0])) else "reduce"
+            reduce_radiance(how)
         barrier()
         elapsed = time.perf_counter() - t0
         rays = r.ray_total() - rays0
         counts, _ = r.live_counts()
-        t_red = 0.0
-        if N > 1:
-            t_red0 = time.perf_counter()
-            for _ in range(5):
-                reduce_radiance()
-            barrier()
-            t_red = (time.perf_counter() - t_red0) / 5
         r.close()
         if N > 1:
-            t = torch.tensor([elapsed, t_red], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, t_red = float(t[0].item()), float(t[1].item())
+            t = torch.tensor([elapsed, t_red, t_gat], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, t_red, t_gat = float(t[0].item()), float(t[1].item()), float(t[2].item())
             q = torch.tensor([rays], dtype=torch.int64, device=cdev); dist.all_reduce(q, op=dist.ReduceOp.SUM); rays = int(q.item())
-        return {"rays": rays, "elapsed": elapsed, "dev_ms": dev_ms, "counts": counts, "spp": spp, "calls": calls, "reduce_s": t_red}
+        return {"rays": rays, "elapsed": elapsed, "dev_ms": dev_ms, "counts": counts, "spp": spp, "calls": calls, "reduce_s": t_red, "gather_s": t_gat, "collective": how}
 
     head = run_job(a.shard, a.scaling)
     rays, elapsed, dev_ms, counts, spp = head["rays"], head["elapsed"], head["dev_ms"], head["counts"], head["spp"]
@@ -406,9 +454,11 @@ def main():
                                                "(ptk_set_iteration_sharding): every launch keeps the single-GPU width; the reduced image is the "
                                                "single-GPU image with N iterations in flight up to the order of the float additions in the reduce"},
                  "unit": "Mrays/s", "headline": f"{a.shard}/{a.scaling}",
-                 "reduce_ms": round(1e3 * head["reduce_s"], 4),
-                 "reduce_note": "one dist.reduce(SUM) of the float32[3*W*H] radiance buffer to rank 0 (+ the device copy into the "
-                                "send buffer), mean of 5, max over ranks; it is inside every timed region once",
+                 "reduce_ms": round(1e3 * head["reduce_s"], 4), "gather_ms": round(1e3 * jobs[("tiles", "weak")]["gather_s"], 4),
+                 "collective_used": {f"{k[0]}/{k[1]}": v["collective"] for k, v in jobs.items()},
+                 "reduce_note": "reduce_ms: one dist.reduce(SUM) of the float32[3*W*H] radiance buffer to rank 0 (+ the device copy into the send buffer); "
+                                "gather_ms: dist.gather of the own row tiles only (1/N of the bytes; tile sharding); mean of 3, max over ranks.  One of them is inside "
+                                "every timed region once: the reduce, unless it costs more than 2 % of a step and the gather is cheaper (--collective auto)",
                  "note": "tiles (weak / strong): every rank traces N / 1 samples of its interleaved row tiles per launch (per-GPU work fixed / "
                          "whole-frame work fixed, per-rank launches shrink by N); iteration_sharded (weak / strong): K*IPS / K*IPS/N "
                          "whole-frame iterations per rank"}
@@ -456,6 +506,18 @@ def main():
             rr.close()
             ref_order = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(1e3 * tt / a.steps, 4), "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
                          "config": "iterations_in_flight 1, graph_replay false: the reference's accumulation order, bit-identical image"}
+        if ref_order is not None and a.tiles <= 1:
+            # the same accumulation order — the image is bit-identical to reference_order's — with three bands of rows in flight (ptk_set_tiles_in_flight)
+            rt = ptk.Renderer(scene, mode, pipeline=a.pipeline, tiles=3, graph=True)
+            for i in range(1, a.warmup * IPS + 1):
+                rt.iterate(i)
+            rt.sync(); q0 = rt.ray_total(); tt0 = time.perf_counter()
+            for i in range(a.warmup * IPS + 1, (a.warmup + a.steps) * IPS + 1):
+                rt.iterate(i)
+            rt.sync(); tt = time.perf_counter() - tt0; qr = rt.ray_total() - q0
+            rt.close()
+            ref_order["tiles_in_flight"] = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
+                                            "config": "tiles_in_flight 3, graph_replay true: the reference's accumulation order and RNG keys, bit-identical image (tests/test_gpu_parity.py::test_tiles_in_flight*)"}
         cpp_api = None
         exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
         if N == 1 and not a.lean and os.path.exists(exe):
@@ -515,7 +577,7 @@ def main():
                                                            if a.shard == "tiles" else f"whole-frame iterations, rank g renders iterations g+1, g+1+{N}, ...")
                                                           + ", one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
                        "iterations_total": head["calls"] * (N if a.shard == "iterations" else 1) * spp,
-                       "iterations_in_flight": a.in_flight, "graph_replay": bool(a.graph),
+                       "iterations_in_flight": a.in_flight if a.tiles <= 1 else 1, "tiles_in_flight": max(a.tiles, 1), "graph_replay": bool(a.graph),
                        "pipeline": ("one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d (segmented streams, physical-slot hit records, window hit "
                                     "prefixes); device-resident counts, no host sync") if fused else
                                    "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync",
@@ -529,23 +591,27 @@ def main():
         if multi is not None:
             out["multi_gpu"] = multi
         if N == 1:
-            # how busy the vector ALUs are over the TIMED region: VALU-active cycles of every kernel of one iteration (committed
-            # single-stream PMC pass, SQ_ACTIVE_INST_VALU in quad-cycles) / (1024 SIMDs x wall cycles of one iteration at the 2.39 GHz
-            # rocm-smi shows during this run).  With iterations in flight the kernels overlap; their instruction counts do not change.
+            # utilisation from counters taken IN the timed configuration (tools/pmc_timed.sh: one rocprofv3 --pmc pass over `bench.py --lean 1`,
+            # summed over every dispatch), no assumed clock: VALU-active quad-cycles x 4 / (SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) — a fraction of the cycles the
+            # GPU was active in that very run, <= 1 by construction.  Read from the committed summary (PMC collection cannot run inside this process).
+            try:
+                pt = json.load(open(os.path.join(ROOT, PMC_TIMED_FILE)))
+                out["valu_busy_timed"] = {k: pt[k] for k in ("frac", "valu_active_cycles", "gpu_active_cycles_per_xcd", "simds", "effective_clock_GHz", "dispatches", "note", "source") if k in pt}
+            except Exception:
+                pass
+            # the roofline of the TIMED pipeline (not of one kernel alone): algorithmic and counter bytes over the timed wall time
             rec = pmc_record(a.scene) if (scene.width, scene.height) == (800, 800) and res is None and a.depth < 0 else None
-            if rec:
+            alg = rays * BYTES_PER_PATH_BOUNCE / elapsed / 1e9
+            roofline["frac_timed"] = round(alg / HBM_PEAK_GBS, 4)
+            roofline["frac_timed_note"] = "algorithmic bytes of ALL rays of the timed region (224 B per path-bounce) / its wall time / 8 TB/s: the whole pipeline with its overlap, where `frac` is one launch alone on one stream"
+            if rec and fused:
                 per_iter = 0.0
-                per_launch = ({"k_shade_trace": scene.trace_depth, "k_shade_trace_gen": 1} if fused else
-                              {"k_intersect": scene.trace_depth, "k_shade_binned": scene.trace_depth, "k_generate": 1})
-                for k, mult in per_launch.items():
-                    c = (rec.get(k) or {}).get("counters") if isinstance(rec.get(k), dict) else None
-                    if c and "SQ_ACTIVE_INST_VALU" in c:
-                        per_iter += c["SQ_ACTIVE_INST_VALU"] * mult
-                cyc = 4.0 * per_iter / 1024.0
-                out["valu_busy_estimate"] = {"frac": round(cyc / (1e-3 * out["ms_per_iteration"] * 2.39e9), 3), "valu_active_cycles_per_simd_per_iteration": round(cyc),
-                                             "clock_GHz_assumed": 2.39, "source": PMC_FILE,
-                                             "note": "VALU-active quad-cycles of the timed pipeline's kernels (single-stream PMC pass) over the wall time of one iteration; the "
-                                                     "counter charges every instruction one quad-cycle (packed and transcendental instructions issue longer: tools/diag/issue_cost.hip)"}
+                for k, mult in (("k_shade_trace", scene.trace_depth), ("k_shade_trace_gen", 1)):
+                    t = (rec.get(k) or {}).get("traffic_bytes_per_launch") if isinstance(rec.get(k), dict) else None
+                    per_iter += (t or 0) * mult
+                if per_iter > 0:
+                    roofline["frac_timed_measured"] = round(per_iter / (1e-3 * out["ms_per_iteration"]) / 1e9 / HBM_PEAK_GBS, 4)
+                    roofline["frac_timed_measured_note"] = "PMC traffic of one iteration's launches (single-stream pass, %s) / the timed ms_per_iteration / 8 TB/s" % PMC_FILE
         out.update(extra)
         print(json.dumps(out))
     if N > 1:

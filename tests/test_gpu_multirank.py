@@ -140,7 +140,7 @@ def test_bench_self_launches_two_ranks(tmp_path):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-                        "--iters-per-step", "2", "--res", "128", "128", "--profile-steps", "1", "--cpu-seconds", "0"],
+                        "--iters-per-step", "2", "--res", "128", "128", "--profile-steps", "1", "--cpu-seconds", "0", "--collective", "gather"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -151,3 +151,66 @@ def test_bench_self_launches_two_ranks(tmp_path):
     for k in (m["weak"], m["strong"], m["iteration_sharded"]["weak"], m["iteration_sharded"]["strong"]):
         assert k["value"] > 0
     assert m["iteration_sharded"]["strong"]["calls_per_rank"] == 2 and m["iteration_sharded"]["weak"]["calls_per_rank"] == 4
+    # --collective gather: the tile-sharded jobs gathered their own row tiles, the iteration-sharded ones (whole frames everywhere) reduced
+    assert m["collective_used"]["tiles/weak"] == "gather" and m["collective_used"]["iterations/weak"] == "reduce" and m["gather_ms"] > 0
+
+
+def test_bench_nccl_without_enough_gpus_fails_fast():
+    """`--backend nccl` with fewer visible GPUs than ranks exits non-zero with one clear line instead of hanging in RCCL (a rank per
+    device is a hard requirement there; the one-GPU rehearsals use gloo)."""
+    import subprocess
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "nccl", "--steps", "1", "--warmup", "1", "--res", "64", "64"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert f"needs {n} visible GPUs" in (r.stderr + r.stdout), (r.stderr + r.stdout)[-1500:]
+
+
+def _gather_worker(rank, world, port, out_dir, res, depth, rows):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
+    scene = ptk.Scene(os.path.join(ROOT, "scenes", "bunny_cornell.txt"), res=res, depth=depth)
+    r = ptk.Renderer(scene, 0, partition=(world, rank, rows), in_flight=2, graph=True)
+    for step in (1, 2):
+        r.iterate(step)
+    red = torch.zeros((scene.width * scene.height, 3), dtype=torch.float32, device="cuda")
+    r.image_to(red)
+    r.close()
+    # (a) the full-frame SUM-reduce, (b) the gather of the own row tiles, as bench.py does them
+    host = red.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+    counts = [len(ptk.partition_pixels(scene.width, scene.height, world, q, rows).ravel()) for q in range(world)]
+    idx = torch.from_numpy(ptk.partition_pixels(scene.width, scene.height, world, rank, rows).ravel().astype("int64"))
+    part = torch.zeros((max(counts), 3), dtype=torch.float32); part[:len(idx)] = red.cpu().index_select(0, idx)
+    bufs = [torch.zeros_like(part) for _ in range(world)] if rank == 0 else None
+    dist.gather(part, bufs, dst=0)
+    if rank == 0:
+        full = torch.zeros_like(host)
+        for q in range(world):
+            iq = torch.from_numpy(ptk.partition_pixels(scene.width, scene.height, world, q, rows).ravel().astype("int64"))
+            full.index_copy_(0, iq, bufs[q][:counts[q]])
+        np.save(os.path.join(out_dir, "reduced.npy"), host.numpy()); np.save(os.path.join(out_dir, "gathered.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_six_rank_rehearsal_at_configs4_rank_size(tmp_path, ptk):
+    """a one-GPU gloo rehearsal at the PER-RANK size of BASELINE configs[4] (2048 x 2048 / 8 ranks = 524 288 paths per rank, depth 16,
+    8-row tiles, the bunny scene) — with six ranks, the most this pool lets share one card: a 2048 x 1536 frame split six ways is the same 524 288
+    paths per rank.  The gathered own tiles equal the SUM-reduced full frames bit for bit (disjoint supports), and rank 3's part equals the
+    single-process render of that part."""
+    world, res, depth, rows = 6, (2048, 1536), 16, 8
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path), res, depth, rows), nprocs=world, join=True)
+    red = np.load(tmp_path / "reduced.npy"); gat = np.load(tmp_path / "gathered.npy")
+    assert np.array_equal(red, gat) and red.sum() > 0
+    scene = ptk.Scene(os.path.join(ROOT, "scenes", "bunny_cornell.txt"), res=res, depth=depth)
+    assert ptk.lib.ptk_partition_count(res[0], res[1], world, 3, rows) == 2048 * 2048 // 8
+    r = ptk.Renderer(scene, 0, partition=(world, 3, rows), in_flight=2, graph=True)
+    for step in (1, 2):
+        r.iterate(step)
+    mine = r.image(); r.close()
+    px = ptk.partition_pixels(res[0], res[1], world, 3, rows).ravel()
+    assert np.array_equal(mine[px], red[px]) and mine[px].sum() > 0
