@@ -197,12 +197,12 @@ def _gather_worker(rank, world, port, out_dir, res, depth, rows):
     dist.destroy_process_group()
 
 
-def test_six_rank_rehearsal_at_configs4_rank_size(tmp_path, ptk):
+def test_five_rank_rehearsal_at_configs4_rank_size(tmp_path, ptk):
     """a one-GPU gloo rehearsal at the PER-RANK size of BASELINE configs[4] (2048 x 2048 / 8 ranks = 524 288 paths per rank, depth 16,
-    8-row tiles, the bunny scene) — with six ranks, the most this pool lets share one card: a 2048 x 1536 frame split six ways is the same 524 288
-    paths per rank.  The gathered own tiles equal the SUM-reduced full frames bit for bit (disjoint supports), and rank 3's part equals the
-    single-process render of that part."""
-    world, res, depth, rows = 6, (2048, 1536), 16, 8
+    8-row tiles, the bunny scene) — with five ranks, the most this pool lets share one card beside the test process itself (six processes per GPU):
+    a 2048 x 1280 frame split five ways is the same 524 288 paths per rank.  The gathered own tiles equal the SUM-reduced full frames bit for
+    bit (disjoint supports), and rank 3's part equals the single-process render of that part."""
+    world, res, depth, rows = 5, (2048, 1280), 16, 8
     mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path), res, depth, rows), nprocs=world, join=True)
     red = np.load(tmp_path / "reduced.npy"); gat = np.load(tmp_path / "gathered.npy")
     assert np.array_equal(red, gat) and red.sum() > 0
