@@ -113,6 +113,11 @@ int  ptk_scene_get_materials(const PtkScene* s, PtkMaterial* out);
 int  ptk_scene_get_triangles(const PtkScene* s, PtkTriangle* out);
 int  ptk_scene_get_bvh(const PtkScene* s, PtkBvhNode* out);          /* 6 * bvh_size nodes */
 int  ptk_scene_get_lights(const PtkScene* s, PtkLight* out);
+/* Device bytes of the BVH tables of an uploaded scene: out4 = {threaded nodes (one or six direction-ordered copies of BVH.cpp:180-239's table, 32 B
+ * per node), 8-wide nodes, 8-wide leaf records, leaf-rank table}.  A mesh of more than 1 024 triangles is uploaded with the direction-0 copy and
+ * the rank table that makes any walk order return the reference's winner on exact ties (csrc/ptk_device.hpp, "ONE COPY INSTEAD OF SIX"; SURVEY
+ * 8f-4: removal of the 6x MTBVH duplication); ptk_set_pipeline(5) and the traversal counters re-upload all six. */
+int  ptk_scene_bvh_device_bytes(const PtkScene* s, unsigned long long* out4);
 /* The 8-wide collapsed form of the same BVH (src/BVH.cpp:13-239 builds the binary tree; the collapse and why it is
  * parity-preserving: csrc/wide_bvh.h).  counts[4] = wide nodes (0: the tree cannot be collapsed, the threaded walk is
  * used), leaf records, levels, per-ray stack bound.  nodes: 144 B each, leaves: 64 B each (layout: csrc/ptk_device.hpp). */

@@ -38,7 +38,7 @@ E_BADARG, E_NOSCENE, E_PARSE, E_NODEVICE = 1001, 1002, 1003, 1004
 ABI_SYMBOLS = [
     "ptk_scene_load", "ptk_scene_free", "ptk_scene_error", "ptk_scene_counts", "ptk_scene_get_camera",
     "ptk_scene_get_geoms", "ptk_scene_get_materials", "ptk_scene_get_triangles", "ptk_scene_get_bvh",
-    "ptk_scene_get_lights", "ptk_scene_wide_bvh_counts", "ptk_scene_get_wide_bvh", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
+    "ptk_scene_get_lights", "ptk_scene_bvh_device_bytes", "ptk_scene_wide_bvh_counts", "ptk_scene_get_wide_bvh", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
     "ptk_shade", "ptk_tonemap", "ptk_pathtrace_init", "ptk_pathtrace_free", "ptk_pathtrace",
     "ptk_set_sample_mode", "ptk_get_sample_mode", "ptk_get_image", "ptk_get_image_device",
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
@@ -120,6 +120,7 @@ def _load() -> C.CDLL:
         getattr(lib, "ptk_scene_" + name).argtypes = [vp, vp]
     lib.ptk_scene_upload.argtypes = [vp]
     lib.ptk_scene_wide_bvh_counts.argtypes = [vp, vp]
+    lib.ptk_scene_bvh_device_bytes.argtypes = [vp, vp]
     lib.ptk_scene_get_wide_bvh.argtypes = [vp, vp, vp]
     lib.ptk_scene_get_texture_size.argtypes = [vp, ci, vp, vp]
     lib.ptk_scene_get_texture.argtypes = [vp, ci, vp]
@@ -206,6 +207,12 @@ class Scene:
         if c[0] > 0:
             _chk(lib.ptk_scene_get_wide_bvh(self.handle, nodes.ctypes.data, leaves.ctypes.data), "ptk_scene_get_wide_bvh")
         return nodes, leaves, int(c[2]), int(c[3])
+
+    def bvh_device_bytes(self):
+        """-> (threaded nodes, wide nodes, wide leaves, rank table) bytes on the device (after upload())"""
+        out = np.zeros(4, np.uint64)
+        _chk(lib.ptk_scene_bvh_device_bytes(self.handle, out.ctypes.data), "ptk_scene_bvh_device_bytes")
+        return tuple(int(x) for x in out)
 
     def texture(self, i: int) -> np.ndarray:
         """float32 [h, w, 3], row 0 = bottom row (as the reference loads it)"""

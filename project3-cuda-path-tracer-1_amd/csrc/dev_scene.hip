@@ -134,17 +134,6 @@ int DevScene::initiate(Scene& scene) {
         m[i].normal_tex = (s.normalMapID >= 0 && s.normalMapID < T) ? s.normalMapID : -1;
     }
     const int B = scene.bvhSize;
-    std::vector<DevNode> nodes((size_t)6 * B);
-    for (size_t i = 0; i < nodes.size(); ++i) {
-        const GpuBVHNode& n = scene.gpuBVHNodes[i];
-        DevNode o{n.pMin.x, n.pMin.y, n.pMin.z, n.pMax.x, n.pMax.y, n.pMax.z, 0, 0};
-        if (n.end - n.start <= 1) {                 // leaf (MAX_PRIM = 1): hit link == miss link by construction (BVH.cpp:200-236)
-            if (n.hit != n.miss) return PTK_E_BADARG;
-            o.a = n.end > n.start ? -(n.start + 2) : -1;
-            o.b = n.hit;
-        } else { o.a = n.hit; o.b = n.miss; }
-        nodes[i] = o;
-    }
     std::vector<DevTriE> te(scene.triangles.size());
     std::vector<DevTriV> tv(scene.triangles.size());
     std::vector<DevTriA> ta(scene.triangles.size());
@@ -173,7 +162,6 @@ int DevScene::initiate(Scene& scene) {
     if ((rc = upload(&dev_gbox, gb))) return rc;
     if ((rc = upload(&dev_gmask, gm))) return rc;
     if ((rc = upload(&dev_materials, m))) return rc;
-    if ((rc = upload(&dev_nodes, nodes))) return rc;
     if ((rc = upload(&dev_trie, te))) return rc;
     wide_nodes = wide_depth = wide_stack = 0;
     if (!scene.triangles.empty()) {                          // 8-wide collapsed form of the same tree (wide_bvh.h)
@@ -184,21 +172,67 @@ int DevScene::initiate(Scene& scene) {
             wide_nodes = (int)wb.nodes.size(); wide_depth = wb.depth; wide_stack = wb.max_stack;
         }
     }
+    tri_num = (int)tv.size(); bvh_size = B;
+    // Threaded copies (ptk_device.hpp, "ONE COPY INSTEAD OF SIX"): meshes the render loop walks inside the fused kernel (<= 1 024 triangles, where the
+    // nearer-first order is the walk's speed) and meshes without a wide tree keep all six; a large mesh gets the direction-0 copy + the rank table.
+    // PTK_THREADED_COPIES=1|6 overrides (tests run both); ptk_set_pipeline(5) / the traversal counters re-upload six (upload_threaded).
+    int copies = (wide_nodes > 0 && tri_num > 1024) ? 1 : 6;
+    if (const char* e = getenv("PTK_THREADED_COPIES")) { const int c = atoi(e); if (c == 6 || (c == 1 && tri_num > 0)) copies = c; }
+    if ((rc = upload_threaded(scene, copies))) return rc;
     if ((rc = upload(&dev_triv, tv))) return rc;
     if ((rc = upload(&dev_tria, ta))) return rc;
     if ((rc = upload(&dev_lights, li))) return rc;
     if ((rc = upload(&dev_textures, tx))) return rc;
     if ((rc = upload(&dev_texture_data, texels))) return rc;
     tex_num = (int)tx.size(); envMapID = scene.envMapID;
-    tri_num = (int)tv.size(); bvh_size = B;
     uploaded = true;
     return 0;
 }
 
+int DevScene::upload_threaded(Scene& scene, int copies) {
+    if (copies != 1 && copies != 6) return PTK_E_BADARG;
+    if (n_copies == copies && dev_nodes) return 0;
+    const int B = scene.bvhSize, T = (int)scene.triangles.size();
+    std::vector<DevNode> nodes((size_t)copies * B);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const GpuBVHNode& n = scene.gpuBVHNodes[i];
+        DevNode o{n.pMin.x, n.pMin.y, n.pMin.z, n.pMax.x, n.pMax.y, n.pMax.z, 0, 0};
+        if (n.end - n.start <= 1) {                 // leaf (MAX_PRIM = 1): hit link == miss link by construction (BVH.cpp:200-236)
+            if (n.hit != n.miss) return PTK_E_BADARG;
+            o.a = n.end > n.start ? -(n.start + 2) : -1;
+            o.b = n.hit;
+        } else { o.a = n.hit; o.b = n.miss; }
+        nodes[i] = o;
+    }
+    std::vector<uint32_t> ranks;
+    if (copies == 1) {
+        // position of every triangle in each direction's leaf order: follow the hit links of that direction's copy (they visit every node)
+        ranks.assign((size_t)6 * T, 0u);
+        for (int d = 0; d < 6; ++d) {
+            uint32_t r = 0; int i = 0, guard = 0;
+            while (i != -1 && guard++ <= B) {
+                const GpuBVHNode& n = scene.gpuBVHNodes[(size_t)d * B + i];
+                if (n.end - n.start == 1 && n.start >= 0 && n.start < T) ranks[(size_t)d * T + n.start] = r++;
+                i = n.hit;
+            }
+            if ((int)r != T) return PTK_E_BADARG;           // not a tree with one triangle per leaf: keep six copies instead
+        }
+    }
+    void* new_nodes = nullptr; void* new_ranks = nullptr;
+    int rc;
+    if ((rc = upload(&new_nodes, nodes))) return rc;
+    if (copies == 1 && (rc = upload(&new_ranks, ranks))) { (void)hipFree(new_nodes); return rc; }
+    if (dev_nodes || dev_ranks) (void)hipDeviceSynchronize();      // a re-upload (pipeline 5 / traversal counters): nothing may still be reading the old tables
+    if (dev_nodes) (void)hipFree(dev_nodes);
+    if (dev_ranks) (void)hipFree(dev_ranks);
+    dev_nodes = new_nodes; dev_ranks = new_ranks; n_copies = copies;
+    return 0;
+}
+
 void DevScene::destroy() {
-    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_trie, &dev_wnodes, &dev_wleaves, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
+    void** ptrs[] = {&dev_geoms, &dev_gbox, &dev_gmask, &dev_materials, &dev_nodes, &dev_ranks, &dev_trie, &dev_wnodes, &dev_wleaves, &dev_triv, &dev_tria, &dev_lights, &dev_textures, &dev_texture_data};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    wide_nodes = 0;
+    wide_nodes = 0; n_copies = 0;
     uploaded = false;
 }
 
@@ -324,6 +358,17 @@ int ptk_scene_get_wide_bvh(const PtkScene* s, void* nodes, void* leaves) {
     if (s->scene->triangles.empty() || !build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb)) return PTK_E_BADARG;
     std::memcpy(nodes, wb.nodes.data(), wb.nodes.size() * sizeof(WideNodeHost));
     std::memcpy(leaves, wb.leaves.data(), wb.leaves.size() * sizeof(WideLeafHost));
+    return 0;
+}
+
+int ptk_scene_bvh_device_bytes(const PtkScene* s, unsigned long long* out4) {
+    if (!s || !s->scene || !out4) return PTK_E_BADARG;
+    const DevScene& d = s->scene->tempDevScene;
+    if (!d.uploaded) return PTK_E_NOSCENE;
+    out4[0] = (unsigned long long)d.n_copies * d.bvh_size * sizeof(DevNode);
+    out4[1] = (unsigned long long)d.wide_nodes * 144ull;
+    out4[2] = d.dev_wleaves ? (unsigned long long)d.tri_num * 64ull : 0ull;
+    out4[3] = d.dev_ranks ? 6ull * d.tri_num * sizeof(uint32_t) : 0ull;
     return 0;
 }
 

@@ -289,6 +289,7 @@ int context_init(Scene* scene) {
     if (n_planes > 1) { if ((rc = dalloc(&g.image, plane))) return rc; } else g.image = g.planes;
     if ((rc = dalloc(&g.ray_total, 1))) return rc;
     if ((e = hipMemset(g.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return (int)e;
+    if (g.pipeline == 5 && scene->tempDevScene.n_copies != 6 && (rc = scene->tempDevScene.upload_threaded(*scene, 6))) return rc;
     g.lanes.assign(g.n_lanes, Lane());
     for (int i = 0; i < g.n_lanes; ++i) if ((rc = lane_init(g.lanes[i], i))) return rc;
     g.last_lane = 0;
@@ -597,6 +598,16 @@ int ptk_set_iterations_in_flight(int lanes) {
  * 0 = one path per thread in path order (honoured by pipeline 4 only: block-local compaction needs the binned kernel).
  * 512- and 1024-path bins were measured slower and are gone.  Identical results. */
 static void invalidate_graphs() { for (Lane& l : g.lanes) l.graph_mode = -1; }     // captured launches bake these knobs in: recapture
+// The reference's own threaded walk as the work-list walk (pipeline 5) and the traversal counters (whose numbers describe that walk, direction
+// order included) need all six direction copies; a large mesh is uploaded with one (dev_scene.hip).  Re-upload on demand; captured graphs hold
+// the old table's address.
+static int need_six_copies() {
+    if (!g.scene || !g.scene->tempDevScene.uploaded || g.scene->tempDevScene.n_copies == 6) return 0;
+    sync_all();
+    const int rc = g.scene->tempDevScene.upload_threaded(*g.scene, 6);
+    invalidate_graphs();
+    return rc;
+}
 int ptk_set_shade_binning(int block) { if (block != 0 && block != 256) return PTK_E_BADARG; set_shade_bin(block); invalidate_graphs(); return 0; }
 /* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
 int ptk_set_light_fix(int on) { set_light_fix(on != 0); invalidate_graphs(); return 0; }
@@ -728,6 +739,7 @@ int ptk_debug_clear_image(void) {
 int ptk_set_pipeline(int which) {
     if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
     if (g.live && g.tiles && !trace_pipeline(which)) return PTK_E_BADARG;
+    if (g.live && which == 5) { const int rc = need_six_copies(); if (rc) return rc; }
     g.pipeline = which;
     for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = pick_lpr(g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     set_uniform_analytic(which == 2);
@@ -764,6 +776,7 @@ int ptk_profile_end(float* ms4, int* launches4) {
 int ptk_enable_traversal_stats(int on) {
     if (!g.live) return PTK_E_NOSCENE;
     if (on && g.tiles) return PTK_E_BADARG;              // (the counters live in the staged kernels, which tiles in flight cannot use)
+    if (on) { const int rc = need_six_copies(); if (rc) return rc; }
     sync_all();
     for (Lane& l : g.lanes) {
         if (on && !l.ws.stats) {

@@ -299,7 +299,9 @@ struct SceneView {
     int lds_geoms;               // > 0: kernels stage the transforms of all n_geoms primitives in LDS (stage_geoms) and run the
                                  // candidate loops; 0: wave-uniform loops over every primitive (scalar loads)
     const DevMaterial* mats;     int n_mats;
-    const DevNode* nodes;        int bvh_size;   // [6][bvh_size]
+    const DevNode* nodes;        int bvh_size;   // [n_copies][bvh_size]: six direction-ordered copies, or the direction-0 copy alone (round 4)
+    int n_copies;                // 6 or 1
+    const uint32_t* ranks;       // [6][n_tris] with one copy: rank of triangle t in direction d's leaf order (ranks[d * n_tris + t]); null with six
     const DevTriE* trie;         // traversal form of the triangles
     const uint4* wnodes;         int n_wnodes;   // 8-wide collapsed form of the same tree (WideNode, 9 x uint4 = 144 B each); null = none
     const uint4* wleaves;        // WideLeaf records (4 x uint4 each), children of one wide node consecutive
@@ -802,11 +804,21 @@ PTK_DI void analytic_record_staged(const float* xf, const Analytic& a, Hit& h) {
     h.mat = __float_as_int(r[34]); h.geom = a.geom; h.tri = -1;
 }
 // (2) one traversal state per ray: threaded (stackless) walk over the direction-ordered nodes (pathtrace.cu:236-279)
-struct Walk { f3 o, d, inv; float t_min; int tri; float u, v; int idx; const DevNode* nodes; bool general; };
+// ONE COPY INSTEAD OF SIX (round 4).  The reference threads its tree six times so that a ray visits the nearer child first (BVH.cpp:180-239); the
+// order has two effects: how soon t_min shrinks (speed only) and WHICH triangle wins among exactly equal distances — the first one visited,
+// because the update is strict (pathtrace.cu:262-267).  No other effect: a leaf is skipped only when it cannot lower t_min, so the winner is
+// argmin (t, position in the direction's leaf order) over the leaves whose own tests pass.  With the position of every triangle in each of the
+// six leaf orders in a table (SceneView::ranks), a walk in ANY order returns the reference's winner: accept on t_min > t, or on t_min == t when
+// the new triangle comes earlier in the ray's direction order.  The large-mesh default therefore uploads the direction-0 copy only — it serves
+// the walks that run beside the 8-wide tree (k_tail, the fallback rays of k_traverse_wide, the threaded A/B walk) and every shadow ray (an
+// any-hit: order-free anyway); small meshes walked inside the fused kernel keep six copies (the nearer-first order is their speed).
+struct Walk { f3 o, d, inv; float t_min; int tri; float u, v; int idx; const DevNode* nodes; bool general; const uint32_t* rank; };
 PTK_DI void walk_begin(const SceneView& S, f3 ro, f3 rd, float t_min, Walk& w) {
     w.o = ro; w.d = rd; w.inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     w.t_min = t_min; w.tri = -1; w.u = 0.f; w.v = 0.f; w.idx = 0;
-    w.nodes = S.nodes + (size_t)mtbvh_dir(rd) * S.bvh_size;
+    const int dir = mtbvh_dir(rd);
+    w.nodes = S.nodes + (size_t)(S.n_copies == 6 ? dir : 0) * S.bvh_size;
+    w.rank = S.n_copies == 6 ? nullptr : S.ranks + (size_t)dir * S.n_tris;
     w.general = (rd.x == 0) || (rd.y == 0) || (rd.z == 0);       // needs the containment tests of Bounds3.hpp:174-177
 }
 // one node visit; returns the number of triangle tests it did (0/1).  When w.idx becomes -1 the walk is complete.
@@ -825,7 +837,11 @@ PTK_DI int walk_apply(const SceneView& S, Walk& w, const DevNode& nd) {
         const int k = -(nd.a + 2);
         float tt, u, v;
         tests = 1;
-        if (tri_test(S.trie[k], w.o, w.d, tt, u, v) && w.t_min > tt) { w.t_min = tt; w.tri = k; w.u = u; w.v = v; }
+        if (tri_test(S.trie[k], w.o, w.d, tt, u, v)) {
+            bool take = w.t_min > tt;
+            if (!take && w.rank && w.t_min == tt && w.tri >= 0) take = w.rank[k] < w.rank[w.tri];      // exact tie, walked out of the direction's order
+            if (take) { w.t_min = tt; w.tri = k; w.u = u; w.v = v; }
+        }
     }
     w.idx = nd.b;
     return tests;
@@ -925,7 +941,7 @@ PTK_DI bool occluded_analytic(const SceneView& S, const GeomStage& gs, f3 ori, f
 }
 PTK_DI bool occluded_bvh(const SceneView& S, f3 ori, f3 dir, float minT) {
     if (S.n_tris == 0) return false;
-    const DevNode* nodes = S.nodes + (size_t)mtbvh_dir(dir) * S.bvh_size;
+    const DevNode* nodes = S.nodes;                    // an any-hit is order-free: every shadow ray walks the direction-0 copy (one 640-KB table in L2 instead of six)
     f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const bool general = (dir.x == 0) || (dir.y == 0) || (dir.z == 0);
     int idx = 0;

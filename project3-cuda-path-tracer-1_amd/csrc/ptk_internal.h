@@ -31,6 +31,7 @@ inline SceneView dev_view(const ::Scene& s) {
     d.lds_geoms = (d.n_geoms > 0 && d.n_geoms <= PTK_LDS_GEOMS_MAX && !uniform_analytic()) ? d.n_geoms : 0;
     d.mats = (const DevMaterial*)t.dev_materials; d.n_mats = (int)s.materials.size();
     d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
+    d.n_copies = t.n_copies;                     d.ranks = (const uint32_t*)t.dev_ranks;
     d.trie = (const DevTriE*)t.dev_trie;
     d.wnodes = (const uint4*)t.dev_wnodes;       d.n_wnodes = t.wide_nodes;
     d.wleaves = (const uint4*)t.dev_wleaves;

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, PTK_INTERSECT_WAVES) k_intersect(Sc
             flag = a.geom >= 0;
             if (flag) { if (gs.on) analytic_record_staged(gs.xf, a, h); else analytic_record(S, a, h); }
             // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
-            const DevNode root = S.nodes[(size_t)mtbvh_dir(rd) * S.bvh_size];
+            const DevNode root = S.nodes[0];                       // (the same box in every direction copy)
             float tEnter;
             heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
             if (STATS && !heavy) nv = 1;
@@ -1710,7 +1710,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                                  asm volatile("" :: "v"(h2.n.x), "v"(h2.n.y), "v"(h2.n.z)); }
 #endif
             if (SPLIT) {                       // root box test of this ray's direction tree (the first iteration of pathtrace.cu:249-256)
-                const DevNode root = S.nodes[(size_t)mtbvh_dir(rd) * S.bvh_size];
+                const DevNode root = S.nodes[0];                       // (the same box in every direction copy)
                 float tEnter;
                 heavy = aabb_test(root, ro, rd, mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z), tEnter) && !(tEnter > a.t_min);
             }
@@ -2419,6 +2419,10 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
         if ((e = hipMalloc(&g_abi_hflag, sizeof(int) * (size_t)n)) != hipSuccess) return (int)e;
         if ((e = hipMalloc(&g_abi_hagg, sizeof(int) * (size_t)(grid_for(n) + 1))) != hipSuccess) return (int)e;
         g_abi_list_cap = n;
+    }
+    if (stats && s->scene->tempDevScene.n_copies != 6) {      // the counters describe the reference's own walk, direction order included
+        const int rc6 = s->scene->tempDevScene.upload_threaded(*s->scene, 6);
+        if (rc6) return rc6;
     }
     const SceneView S = dev_view(*s->scene);
     // the render loop's own layout: analytic primitives + root-box test, work list, BVH walk (the 8-wide collapsed tree; with `stats`

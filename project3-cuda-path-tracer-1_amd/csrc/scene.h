@@ -98,13 +98,16 @@ class Scene;
 class DevScene {                                              // scene.h:28-52 — device image of the scene tables
 public:
     int initiate(Scene& scene);                               // returns 0 or a hipError_t
+    int upload_threaded(Scene& scene, int copies);            // (re)uploads 1 or 6 direction-ordered copies of the threaded BVH (+ the leaf ranks with 1)
     void destroy();
     int tri_num = 0, bvh_size = 0;
     void* dev_geoms = nullptr;        // ptk::DevGeom[]
     void* dev_gbox = nullptr;         // ptk::DevGeomBox[]
     void* dev_gmask = nullptr;        // ptk::DevGeomMask[]
     void* dev_materials = nullptr;    // ptk::DevMaterial[]
-    void* dev_nodes = nullptr;        // ptk::DevNode[6][bvh_size]
+    void* dev_nodes = nullptr;        // ptk::DevNode[n_copies][bvh_size]: the threaded BVH, all six direction orders or direction 0 only
+    void* dev_ranks = nullptr;        // uint32[6][tri_num] with ONE copy: position of every triangle in each direction's leaf order (the tie rule, ptk_device.hpp)
+    int n_copies = 0;
     void* dev_trie = nullptr;         // ptk::DevTriE[]
     void* dev_wnodes = nullptr;       // 8-wide collapsed tree (wide_bvh.h), 144 B = 9 x uint4 per node; null if the tree could not be collapsed
     void* dev_wleaves = nullptr;      // its leaf records, 64 B each

@@ -413,6 +413,86 @@ def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, flags, lanes):
     assert np.array_equal(img, ref)
 
 
+def test_large_mesh_uploads_one_threaded_copy(ptk, torch_cuda):
+    """SURVEY 8f-4 / VERDICT r3 #5: the bunny scene's BVH tables on the device — one direction copy of the threaded tree (640 KB) + the rank
+    table (240 KB) + the 8-wide tree and its leaves (1.06 MB) instead of six copies (3.84 MB) + the wide tree; a mesh small enough to be walked
+    inside the fused kernel keeps six (the nearer-first order is its speed)."""
+    s = ptk.Scene(os.path.join(SC, "bunny_cornell.txt")).upload()
+    thr, wn, wl, rk = s.bvh_device_bytes()
+    assert thr == s.bvh_size * 32 and rk == 6 * s.n_triangles * 4 and wn > 0 and wl == s.n_triangles * 64
+    assert thr + wn + wl + rk < 2.0e6, (thr, wn, wl, rk)
+    t = ptk.Scene(os.path.join(SC, "obj_test.txt")).upload()
+    assert t.bvh_device_bytes()[0] == 6 * t.bvh_size * 32 and t.bvh_device_bytes()[3] == 0
+    # pipeline 5 (the reference's own threaded walk over the work list) re-uploads all six, results unchanged
+    r = ptk.Renderer(s, ptk.MODE_BSDF); r.iterate(1); a = r.image(); r.close()
+    r = ptk.Renderer(s, ptk.MODE_BSDF, pipeline=5); r.iterate(1); b = r.image(); r.close()
+    assert s.bvh_device_bytes()[0] == 6 * s.bvh_size * 32 and np.array_equal(a, b)
+    s.close(); t.close()
+
+
+@pytest.mark.parametrize("copies", [1, 6])
+def test_exact_ties_between_triangles(ptk, orc, torch_cuda, tmp_path, monkeypatch, copies):
+    """A mesh whose every face is listed twice: EVERY triangle hit is an exact tie between two triangles, and the reference keeps the one its
+    direction-ordered walk meets first (strict t_min > t, pathtrace.cu:262-267).  With six threaded copies the walks visit in that order; with
+    ONE copy (the large-mesh default, forced here by PTK_THREADED_COPIES) they visit in direction 0's order and the rank table decides
+    (ptk_device.hpp, "ONE COPY INSTEAD OF SIX").  triangleID of every hit == the oracle's through every walk there is: the 8-wide work-list walk,
+    its threaded fallback (axis-parallel rays), the threaded work-list walk (pipeline 5), the walk inside the intersect / fused kernels, k_tail."""
+    torch = torch_cuda
+    src = open(os.path.join(SC, "model", "cube.obj")).read().splitlines()
+    faces = [l for l in src if l.startswith("f ")]
+    (tmp_path / "cubedup.obj").write_text("\n".join([l for l in src if not l.startswith("f ")] + faces + faces) + "\n")
+    text = open(os.path.join(SC, "bunny_cornell.txt")).read().replace("../scenes/model/bunny10k.obj", str(tmp_path / "cubedup.obj")).replace("SCALE       5 5 5", "SCALE       3 3 3")
+    path = str(tmp_path / "dup.txt"); open(path, "w").write(text)
+    monkeypatch.setenv("PTK_THREADED_COPIES", str(copies))
+    # kernel by kernel (ptk_intersect: work list + 8-wide walk), hit records incl. triangleID at every bounce
+    _step_by_step(ptk, orc, torch, path, (96, 96), 4, MODES["MIS"], iters=(1,))
+    s = ptk.Scene(path, res=(96, 96), depth=6).upload()
+    assert s.n_triangles == 24 and s.bvh_device_bytes()[0] == copies * s.bvh_size * 32
+    o = orc.Scene(path, res=(96, 96), depth=6)
+    # axis-parallel and random rays through the kernel-level entry point (the fallback walk for zero direction components)
+    rng = np.random.default_rng(5)
+    dirs = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    rays = [((x, y, 3.0), (0, 0, -1)) for x in np.linspace(-1.4, 1.4, 15) for y in np.linspace(0.6, 3.4, 15)]
+    rays += [(tuple(rng.uniform(-4, 4, 3) + (0, 5, 0)), dirs[rng.integers(6)]) for _ in range(600)]
+    for _ in range(400):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        rays.append((tuple(rng.uniform(-4, 4, 3) + (0, 5, 0)), tuple(d)))
+    n = len(rays)
+    paths = np.zeros(n, orc.PATH_DT)
+    paths["o"] = np.array([r[0] for r in rays], np.float32); paths["d"] = np.array([r[1] for r in rays], np.float32)
+    paths["color"] = 1; paths["pixelIndex"] = np.arange(n) % 1024; paths["remainingBounces"] = 4; paths["prevPdf"] = -1
+    ref_is, ref_valid = o.intersect(paths)
+    A = _to_dev(torch, orc.paths_to_soa(paths)); H = ptk.new_paths(n)
+    valid = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ptk.intersect(s, n, A, H, valid)
+    assert np.array_equal(valid.cpu().numpy(), ref_valid)
+    m = ref_valid.astype(bool)
+    _eq_fields(orc.isects_from_soa(*[h.cpu().numpy() for h in H])[m], ref_is[m], what="dup mesh")
+    assert (ref_is["triangleID"][m] >= 0).sum() > 100
+    # the render loop: fused kernel with the walk inside (0), work list + wide walk (6 / 10), threaded work-list walk (5), walk inside k_intersect (1)
+    ref = np.zeros((o.P, 3), np.float32)
+    lives = []
+    for it in (1, 2, 3):
+        _, live = o.pathtrace(orc.MODE_MIS, it, ref); lives.append(live)
+    for pipe in (0, 10, 6, 5, 1):
+        r = ptk.Renderer(s, ptk.MODE_MIS, pipeline=pipe)
+        for it in (1, 2, 3):
+            r.iterate(it)
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, lives[it - 1]), (pipe, it)
+        assert np.array_equal(r.image(), ref), pipe
+        r.close()
+    s.close()
+    # 22 x 22 = 484 paths: every bounce after the first is under half of k_tail's 1 024-path threshold (the hysteresis of the hand-over), its in-lane walk takes over
+    s2 = ptk.Scene(path, res=(22, 22), depth=8).upload(); o2 = orc.Scene(path, res=(22, 22), depth=8)
+    ref2 = np.zeros((o2.P, 3), np.float32)
+    r = ptk.Renderer(s2, ptk.MODE_BSDF)
+    for it in range(1, 13):
+        r.iterate(it); o2.pathtrace(orc.MODE_BSDF, it, ref2)
+    assert r.full_width_bounces() < 8 and np.array_equal(r.image(), ref2)
+    r.close(); s2.close()
+
+
 def test_compact_edges(ptk, torch_cuda):
     """Stable compaction: empty, single, block-boundary and ragged sizes, all-dead / all-alive / random flags."""
     torch = torch_cuda
