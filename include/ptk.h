@@ -180,10 +180,6 @@ int ptk_set_iterations_in_flight(int lanes);
  * own radiance plane; the image is the sum of the planes in order.  Used with the tile partition so that a rank that owns
  * 1/N of the pixels still launches full-size kernels (multi-GPU weak scaling).  Not a reference feature. */
 int ptk_set_samples_per_launch(int spp);
-/* Shading kernel layout: 256 (default) = each block of 256 consecutive paths is counting-sorted by material type in LDS before
- * shading, to cut BSDF-switch divergence; 0 = one path per thread in path order (honoured by pipeline 4 only).  Every path keeps
- * its own RNG key and state, so results are identical. */
-int ptk_set_shade_binning(int block);
 /* Opt-in "fixed" cube lights.  The reference's LightSampler gives cube lights neither a sampled position nor a
  * pdf (lightSample.h:141-248): MIS renders of cube-lit scenes (cornell.txt) are darkened and direct lighting from them is
  * black.  on = 1: a cube light is sampled uniformly over its surface (face in proportion to world-space area) with the
@@ -243,16 +239,12 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *       are enabled the staged kernels of 8 run instead (they keep the counters);
  *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the
  *       survivors, and the window prefix in a separate one-block k_segments launch (7) or in the last block of the shading kernel (8);
- *   1 = like 7, the BVH is walked inside the intersect kernel for every ray, one ray per lane;
- *   2 = like 1, and analytic primitives are tested with wave-uniform loops over every primitive instead of the LDS-staged
- *       candidate pair lists;
- *   3 = (removed in round 3; PTK_E_BADARG) the ticketed one-kernel-per-bounce fusion of rounds 1-2, whose ticket counter serialised
- *       block starts; k_shade_trace fuses without any inter-block communication;
- *   4 = like 7 with the survivors moved by a separate stable scatter pass (k_scatter) instead of the window tables;
- *   5 = like 7/8, the work-list rays walk the reference's threaded 6-direction BVH, one ray per lane (the others walk the 8-wide
- *       collapsed form of the same tree, several lanes per ray, csrc/wide_bvh.h); 6 = the wide walk with the staged kernels;
- *   9 = like 7/8, every bounce launched at full width (0, 7 and 8 finish the sparse end of an iteration in one single-workgroup
- *       k_tail launch once earlier iterations have shown that few paths survive). */
+ *   1 = like 7, the BVH is walked inside the intersect kernel for every ray, one ray per lane (no k_tail);
+ *   5 = like 7/8, the work-list rays walk the reference's threaded 6-direction BVH, one ray per lane (re-uploads all six direction copies; the
+ *       others walk the 8-wide collapsed form of the same tree, several lanes per ray, csrc/wide_bvh.h); 6 = the wide walk with the staged kernels;
+ *   2, 3, 4, 9 = retired A/B layouts (PTK_E_BADARG): 3 the ticketed one-kernel-per-bounce fusion of rounds 1-2 (round 3: its ticket counter
+ *       serialised block starts); 2 wave-uniform primitive loops instead of the LDS pair lists, 4 survivors moved by a stable scatter pass
+ *       instead of the window tables, 9 every bounce at full width without k_tail (round 4: each lost its measurement in rounds 1-3). */
 int ptk_set_pipeline(int which);
 int ptk_stream_sync(void);
 

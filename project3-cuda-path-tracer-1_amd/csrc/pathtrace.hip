@@ -172,7 +172,7 @@ static int pick_walk(int pipeline, int n_lanes) {
 // clear of the bunny class.  Identical results either way (PTK_INLINE_BVH_MAX_TRIS overrides it for A/B runs).
 constexpr int kInlineBvhMaxTris = 1024;
 bool inline_bvh_choice(int which) {
-    if (which == 1 || which == 2) return true;
+    if (which == 1) return true;
     static const int max_tris = getenv("PTK_INLINE_BVH_MAX_TRIS") ? atoi(getenv("PTK_INLINE_BVH_MAX_TRIS")) : kInlineBvhMaxTris;      // (A/B knob)
     return which == 0 && g.scene && g.scene->tempDevScene.tri_num > 0 && g.scene->tempDevScene.tri_num <= max_tris;
 }
@@ -246,7 +246,6 @@ int lane_init(Lane& l, int idx) {
     l.ws.inline_bvh = inline_bvh_choice(g.pipeline);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.wide_lpr = pick_lpr(g.n_lanes);            // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
-    l.ws.segmented = (g.pipeline != 4);
     l.ws.capacity = l.capacity;
     l.last_iter = 0;
     return 0;
@@ -319,8 +318,8 @@ void prof_mark(int cls, bool begin) {
     if (begin) g_prof.cls.push_back(cls);
 }
 
-// k_tail finishes the iterations of the default (segmented) pipelines; pipeline 9 = every bounce at full width (A/B)
-bool sparse_tail() { return g.pipeline != 9 && g.pipeline != 4 && g.pipeline != 1 && g.pipeline != 2 && !g_prof.on &&
+// k_tail finishes the iterations of every pipeline but 1 (and never under the per-kernel profiler or with the traversal counters on)
+bool sparse_tail() { return g.pipeline != 1 && !g_prof.on &&
                             !(g.lanes.size() && g.lanes[0].ws.stats); }
 // the fused shade + trace launches: pipeline 10 always, pipeline 0 (auto) for triangle-free scenes — with a BVH stage behind every launch
 // the staged kernels are 1-3 % ahead (bunny scene 5.70 vs 5.62 Grays/s); the traversal counters are only kept by the staged kernels
@@ -594,9 +593,6 @@ int ptk_set_iterations_in_flight(int lanes) {
     return 0;
 }
 
-/* Shading kernel layout: 256 (default) = the paths of each 256-path block are counting-sorted by material type before shading;
- * 0 = one path per thread in path order (honoured by pipeline 4 only: block-local compaction needs the binned kernel).
- * 512- and 1024-path bins were measured slower and are gone.  Identical results. */
 static void invalidate_graphs() { for (Lane& l : g.lanes) l.graph_mode = -1; }     // captured launches bake these knobs in: recapture
 // The reference's own threaded walk as the work-list walk (pipeline 5) and the traversal counters (whose numbers describe that walk, direction
 // order included) need all six direction copies; a large mesh is uploaded with one (dev_scene.hip).  Re-upload on demand; captured graphs hold
@@ -608,7 +604,6 @@ static int need_six_copies() {
     invalidate_graphs();
     return rc;
 }
-int ptk_set_shade_binning(int block) { if (block != 0 && block != 256) return PTK_E_BADARG; set_shade_bin(block); invalidate_graphs(); return 0; }
 /* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
 int ptk_set_light_fix(int on) { set_light_fix(on != 0); invalidate_graphs(); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
@@ -737,12 +732,11 @@ int ptk_debug_clear_image(void) {
 }
 #endif
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 10 || which == 3) return PTK_E_BADARG;      // 3 (ticketed fusion, rounds 1-2) is gone: k_shade_trace superseded it
+    if (which < 0 || which > 10 || which == 2 || which == 3 || which == 4 || which == 9) return PTK_E_BADARG;      // retired A/B layouts: 3 (ticketed fusion, round 3); 2 (wave-uniform primitive loops), 4 (scatter-pass compaction), 9 (no k_tail) in round 4
     if (g.live && g.tiles && !trace_pipeline(which)) return PTK_E_BADARG;
     if (g.live && which == 5) { const int rc = need_six_copies(); if (rc) return rc; }
     g.pipeline = which;
-    for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.segmented = (which != 4); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = pick_lpr(g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
-    set_uniform_analytic(which == 2);
+    for (Lane& l : g.lanes) { l.ws.inline_bvh = inline_bvh_choice(which); l.ws.walk = pick_walk(which, g.n_lanes); l.ws.wide_lpr = pick_lpr(g.n_lanes); l.ws.seg_done = fold_segments(which, g.n_lanes) ? l.seg_done_mem : nullptr; }
     invalidate_graphs();
     // the hints were learnt from the other pipeline's counters (hcounts[] is only written by the hit-dense launches): start again, like a
     // sample-mode switch does

@@ -19,8 +19,6 @@ enum { PTK_CUM_RING = 4 };       // iterations a band may run ahead of the band 
 
 void set_light_fix(bool on);            // opt-in fixed cube lights (ptk_set_light_fix)
 bool light_fix_enabled();
-void set_uniform_analytic(bool on);     // A/B: disable the staged candidate loops (ptk_set_pipeline(2))
-bool uniform_analytic();
 
 // device view of an uploaded scene (pointers into DevScene's buffers), passed to kernels by value
 inline SceneView dev_view(const ::Scene& s) {
@@ -28,7 +26,7 @@ inline SceneView dev_view(const ::Scene& s) {
     const ::DevScene& t = s.tempDevScene;
     d.geoms = (const DevGeom*)t.dev_geoms;       d.n_geoms = (int)s.geoms.size();
     d.gbox = (const DevGeomBox*)t.dev_gbox;      d.gmask = (const DevGeomMask*)t.dev_gmask;
-    d.lds_geoms = (d.n_geoms > 0 && d.n_geoms <= PTK_LDS_GEOMS_MAX && !uniform_analytic()) ? d.n_geoms : 0;
+    d.lds_geoms = (d.n_geoms > 0 && d.n_geoms <= PTK_LDS_GEOMS_MAX) ? d.n_geoms : 0;
     d.mats = (const DevMaterial*)t.dev_materials; d.n_mats = (int)s.materials.size();
     d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
     d.n_copies = t.n_copies;                     d.ranks = (const uint32_t*)t.dev_ranks;
@@ -64,7 +62,6 @@ struct Workspace {               // per-render-context scratch, device memory
     int* srcidx = nullptr; int* seg_pref = nullptr; int* seg_first = nullptr;
     int* seg_done = nullptr;     // blocks of the running shading kernel that have published their survivor count (segments_tail); null:
                                  // a separate k_segments launch does the bookkeeping (pipeline 7, A/B)
-    bool segmented = true;       // false: k_scatter moves the survivors (pipeline 4)
     bool inline_bvh = false;     // true: one-ray-per-lane traversal inside k_intersect (A/B comparison)
     // fused pipeline (k_shade_trace): per-window hit counts and their prefix, the SPLIT stage's per-slot flags
     int* agg_h = nullptr; int* hit_pref = nullptr; int* tr_valid = nullptr; int* tr_heavy = nullptr;
@@ -93,7 +90,6 @@ struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; };
 int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool));
-void set_shade_bin(int nt);
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);
 

@@ -988,32 +988,20 @@ __device__ __forceinline__ int shade_path(const SceneView& S, const GeomStage& g
     return alive;
 }
 
-// VIRTUAL = false: thread index is the compacted slot (the reference's launch shape, used by ptk_shade).
-// VIRTUAL = true : paths are still in pre-compaction order; valid_a/agg_a from k_intersect give each hit path its slot.
-template <int MODE, bool VIRTUAL>
-__global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n,
-                                                      PtkHits hits, PtkPaths paths, const int* __restrict__ valid_a,
-                                                      const int* __restrict__ agg_a, int* __restrict__ valid_b,
-                                                      int* __restrict__ agg_b, float* __restrict__ img_base, unsigned plane_stride, int spp, int slot_bias) {
+// Thread index = compacted slot: the reference's launch shape.  The kernel behind the kernel-level ptk_shade entry point (the render loops shade
+// with k_shade_trace / k_shade_binned).
+template <int MODE>
+__global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, int depth, int n_arg, const int* __restrict__ d_n,
+                                                      PtkHits hits, PtkPaths paths, int* __restrict__ valid_b, float* __restrict__ img_base) {
     const int n = d_n ? *d_n : n_arg;
-    const int iter = ((iter_ptr ? *iter_ptr : iter_arg) - 1) * spp + 1;     // RNG key: first iteration of this launch's batch
-    const Film img = {img_base, plane_stride};
+    const Film img = {img_base, 0u};
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
     GeomStage gs; gs.xf = nullptr; gs.on = false;
     if (MODE != PTK_MODE_BSDF) gs = stage_geoms(S);          // only the light-sampling modes trace shadow rays
     const int i = b * PTK_BLOCK + threadIdx.x;
-    int flag = (i < n) ? 1 : 0;
-    int slot = i;
-    if (VIRTUAL) {
-        flag = (i < n) ? valid_a[i] : 0;
-        int total;
-        const int local = block_excl_prefix(flag, total);
-        slot = prior_blocks(agg_a, b) + local;
-    }
-    slot += slot_bias;           // tile partition: rank-unique keys (0 on a single GPU)
     int alive = 0;
-    if (flag) {
+    if (i < n) {
         const float4 h0 = ld4(hits.t_n, i), h1 = ld4(hits.p_mat, i);
         const float4 h2 = S.slim_hits ? make_float4(0.f, 0.f, __int_as_float(-1), __int_as_float(-1)) : ld4(hits.uv_ids, i);
         const float4 o4 = ld4(paths.o_pix, i), d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
@@ -1025,16 +1013,11 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, 
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
         const MatTable mt = {nullptr, 0};
-        alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
+        alive = shade_path<MODE>(S, gs, mt, iter_arg, i, depth, h, p, img);
         st4(paths.o_pix, i, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
         st4(paths.d_bnc, i, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
         st4(paths.col_pdf, i, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
-    }
-    if (i < n) valid_b[i] = alive;
-    if (agg_b) {
-        int total;
-        (void)block_excl_prefix(alive, total);
-        if (threadIdx.x == 0) agg_b[b] = total;
+        valid_b[i] = alive;
     }
 }
 
@@ -1137,12 +1120,12 @@ template <int MODE, int NT>
 __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
                                                       const int* __restrict__ d_n, PtkHits hits, PtkPaths paths,
                                                       const int* __restrict__ valid_a, const int* __restrict__ agg_a,
-                                                      int* __restrict__ valid_b, int* __restrict__ agg_b,
+                                                      int* __restrict__ agg_b,
                                                       float* __restrict__ img_base, unsigned plane_stride, int spp, int slot_bias,
                                                       const int* __restrict__ srcidx, PtkPaths seg_out, SegTail seg_tail) {
     // srcidx  : physical slot of every dense path (segmented input stream), nullptr = the stream is dense
-    // seg_out : non-null streams = block-local compaction: survivors go to seg_out[b * NT + rank within the block] and agg_b[b] is
-    //           their number (valid_b unused); null = update the paths in place and flag the survivors in valid_b (k_scatter follows)
+    // seg_out : block-local compaction: survivors go to seg_out[b * NT + rank within the block] and agg_b[b] is their number
+    //           (until round 4 a null seg_out meant "update in place, k_scatter follows" = pipeline 4, retired)
     constexpr int NW = NT / 64, NKEY = 6, SUB = NT / PTK_BLOCK;      // SUB aggregate entries (256-path ranges) per block
     __shared__ int s_cnt[NW][NKEY];
     __shared__ int s_perm[NT];
@@ -1230,11 +1213,6 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
         p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
         p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
         alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img);
-        if (!seg_out.o_pix) {
-            st4(paths.o_pix, ps, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
-            st4(paths.d_bnc, ps, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
-            st4(paths.col_pdf, ps, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
-        }
     }
     PTK_PHASE(1);                                    // 2: loads + shading
     __syncthreads();                       // everyone is done reading s_slot; reuse it for the survivor flags in original order
@@ -1243,11 +1221,10 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
     if (src >= 0) s_slot[src] = alive;
     __syncthreads();
     const int alive_here = s_slot[tid];
-    if (!seg_out.o_pix && i < n) valid_b[i] = alive_here;
     const unsigned long long ab = __ballot(alive_here != 0);
     if (lane == 0) s_red[wid] = __popcll(ab);
     __syncthreads();
-    if (seg_out.o_pix) {                   // block-local compaction (NT == PTK_BLOCK): survivor rank in original order
+    {                                      // block-local compaction (NT == PTK_BLOCK): survivor rank in original order
         int before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { const int c = s_red[w]; before += (w < wid) ? c : 0; total += c; }
@@ -1264,13 +1241,6 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
         else if (tid == 0) agg_b[b] = total;
         PTK_PHASE(1);                                // 4: segment bookkeeping (the last block does the work)
         PTK_PHASE_END(1);
-        return;
-    }
-    if (tid < SUB && (b * SUB + tid) * PTK_BLOCK < n) {
-        int t = 0;
-#pragma unroll
-        for (int w = 0; w < PTK_WAVES; ++w) t += s_red[tid * PTK_WAVES + w];
-        agg_b[b * SUB + tid] = t;
     }
 }
 
@@ -1799,11 +1769,9 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_count(int n_arg, const int* __res
 
 __global__ void __launch_bounds__(PTK_BLOCK) k_scatter(int n_arg, const int* __restrict__ d_n, const int* __restrict__ valid,
                                                         const int* __restrict__ agg, PtkPaths pin, PtkHits hin, PtkPaths pout,
-                                                        PtkHits hout, int* __restrict__ count_out, int* iter_advance, int iter_stride) {
+                                                        PtkHits hout, int* __restrict__ count_out) {
     const int n = d_n ? *d_n : n_arg;
     const int b = blockIdx.x;
-    // last kernel of an iteration: step the device-resident iteration number (nothing else in this kernel reads it)
-    if (iter_advance && b == 0 && threadIdx.x == 0) *iter_advance += iter_stride;
     if (b * PTK_BLOCK >= n) { if (n <= 0 && b == 0 && threadIdx.x == 0 && count_out) *count_out = 0; return; }
     const int i = b * PTK_BLOCK + threadIdx.x;
     const int flag = (i < n) ? valid[i] : 0;
@@ -2104,37 +2072,17 @@ DevCamera to_dev_camera(const PtkCamera& c) {
     return d;
 }
 
-int g_shade_bin = 256;                 // 0: plain k_shade (pipeline 4 only); 256: k_shade_binned (paths of a block sorted by material)
-
-template <int NT>
 int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                        const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
+                        const int* va, const int* aa, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
                         const int* srcidx, PtkPaths seg_out, SegTail seg_tail) {
+    constexpr int NT = PTK_BLOCK;
     const int g = (n + NT - 1) / NT;
     if (g == 0) return 0;
+    if (!seg_out.o_pix) return PTK_E_BADARG;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
-    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
-    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
-    default: return PTK_E_BADARG;
-    }
-    return launch_rc();
-}
-
-template <bool V>
-int launch_shade(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                 const int* va, const int* aa, int* vb, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
-                 const int* srcidx = nullptr, PtkPaths seg_out = PtkPaths{nullptr, nullptr, nullptr},
-                 SegTail seg_tail = SegTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
-    if (V && seg_out.o_pix) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, srcidx, seg_out, seg_tail);
-    if (srcidx) return PTK_E_BADARG;       // only the segmented pipeline addresses paths indirectly
-    if (V && g_shade_bin == 256) return launch_shade_binned<256>(mode, S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias, st, nullptr, seg_out, SegTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
-    const int g = grid_for(n);
-    if (g == 0) return 0;
-    switch (mode) {
-    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF, V><<<g, PTK_BLOCK, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias); break;
-    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias); break;
-    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS, V><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, vb, ab, img, plane_stride, spp, slot_bias); break;
+    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -2145,7 +2093,6 @@ int* g_abi_list = nullptr;
 int g_abi_list_cap = 0;
 int* g_abi_hflag = nullptr;             // work-list flags / per-block counts of the same entry point (same layout as the render loop)
 int* g_abi_hagg = nullptr;
-bool g_uniform_analytic = false;       // A/B switch: wave-uniform loops over every analytic primitive (no LDS staging, no candidate test)
 
 // scratch for the stand-alone ptk_compact entry point (per-block aggregates), grown on demand
 int* g_compact_agg = nullptr;
@@ -2227,9 +2174,9 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
     SceneView S = S_in;
     S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
     // segmented streams: `cur` holds the survivors of the previous bounce window by window (dense at bounce 0)
-    const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && ws.srcidx;
+    if (!ws.seg_pref || !ws.seg_first || !ws.srcidx) return PTK_E_BADARG;
     Gather G = {nullptr, nullptr, nullptr};
-    if (seg && depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
+    if (depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
     // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
                                     ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr);
@@ -2239,24 +2186,15 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
         if ((rc = launch_rc())) return rc;
     }
     mark(2, true);
-    const bool fold = seg && ws.seg_done != nullptr;         // the shading kernel's last block does the window bookkeeping itself
+    const bool fold = ws.seg_done != nullptr;                // the shading kernel's last block does the window bookkeeping itself
     const SegTail tail = {fold ? ws.seg_done : nullptr, ws.seg_pref, ws.seg_first, ws.counts + depth + 1, last_bounce ? ws.iter_dev : nullptr, ws.iter_stride};
-    rc = launch_shade<true>(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.valid_b, ws.agg_b, img, ws.plane_stride, ws.spp,
-                            ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0), st,
-                            G.src, seg ? nxt : PtkPaths{nullptr, nullptr, nullptr}, tail);
+    rc = launch_shade_binned(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.agg_b, img, ws.plane_stride, ws.spp,
+                             ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0), st, G.src, nxt, tail);
     mark(2, false);
     if (rc || fold) return rc;
-    if (seg) {                              // survivors are already in nxt, window by window: only the bookkeeping is left
-        mark(3, true);
-        k_segments<<<1, PTK_SEG_BLOCK, 0, st>>>(capacity, d_n, ws.agg_b, ws.seg_pref, ws.seg_first, ws.counts + depth + 1,
-                                                 last_bounce ? ws.iter_dev : nullptr, ws.iter_stride);
-        mark(3, false);
-        return launch_rc();
-    }
-    PtkHits none = {nullptr, nullptr, nullptr};
-    mark(3, true);
-    k_scatter<<<g, PTK_BLOCK, 0, st>>>(capacity, d_n, ws.valid_b, ws.agg_b, cur, none, nxt, none, ws.counts + depth + 1,
-                                       last_bounce ? ws.iter_dev : nullptr, ws.iter_stride);
+    mark(3, true);                          // survivors are already in nxt, window by window: only the bookkeeping is left
+    k_segments<<<1, PTK_SEG_BLOCK, 0, st>>>(capacity, d_n, ws.agg_b, ws.seg_pref, ws.seg_first, ws.counts + depth + 1,
+                                             last_bounce ? ws.iter_dev : nullptr, ws.iter_stride);
     mark(3, false);
     return launch_rc();
 }
@@ -2364,7 +2302,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     A.hit_dense = (hit_dense && depth0 > 0) ? 1 : 0; A.hit_pref = ws.hit_pref; A.first_h = ws.seg_first_h; A.nhits = ws.hcounts ? ws.hcounts + depth0 : nullptr;
     A.hcounts = ws.hcounts;
     A.cum_prev = ws.cum_prev; A.cum_out = ws.cum_out; A.cum_stride = ws.cum_stride; A.ring_div = ws.ring_div;
-    const bool seg = ws.segmented && ws.seg_pref && ws.seg_first && depth0 > 0;
+    const bool seg = ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
     A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias; A.dbg_shift0 = ws.dbg_shift0; A.dbg_shift_deep = ws.dbg_shift_deep;
     A.ray_total = ws.ray_total; A.iter_advance = ws.iter_dev; A.iter_stride = ws.iter_stride;
@@ -2379,10 +2317,6 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
 bool g_light_fix = false;
 void set_light_fix(bool on) { g_light_fix = on; }
 bool light_fix_enabled() { return g_light_fix; }
-void set_uniform_analytic(bool on) { g_uniform_analytic = on; }
-bool uniform_analytic() { return g_uniform_analytic; }
-void set_shade_bin(int nt) { g_shade_bin = (nt == 256) ? nt : 0; }
-
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st) {
     const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
     k_sum_planes<<<g, PTK_BLOCK, 0, st>>>(planes, n_planes, plane_len, out);
@@ -2452,7 +2386,7 @@ int ptk_compact(int n, const int* d_n, const int* valid, PtkPaths paths_in, PtkH
     }
     k_count<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg);
     int rc = launch_rc(); if (rc) return rc;
-    k_scatter<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg, paths_in, hits_in, paths_out, hits_out, d_count_out, nullptr, 0);
+    k_scatter<<<g, PTK_BLOCK, 0, st>>>(n, d_n, valid, g_compact_agg, paths_in, hits_in, paths_out, hits_out, d_count_out);
     return launch_rc();
 }
 
@@ -2461,7 +2395,16 @@ int ptk_shade(const PtkScene* s, int mode, int iter, int depth, int n, const int
     if (!s || !s->scene || !s->scene->tempDevScene.uploaded) return PTK_E_NOSCENE;
     if (n < 0 || !paths.o_pix || !paths.d_bnc || !paths.col_pdf || !hits.t_n || !hits.p_mat || !hits.uv_ids || !valid || !img) return PTK_E_BADARG;
     if (n == 0) return 0;
-    return launch_shade<false>(mode, dev_view(*s->scene), iter, nullptr, depth, n, d_n, hits, paths, nullptr, nullptr, valid, nullptr, img, 0u, 1, 0, (hipStream_t)stream);
+    const SceneView S = dev_view(*s->scene);
+    const int g = grid_for(n);
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode) {
+    case PTK_MODE_BSDF: k_shade<PTK_MODE_BSDF><<<g, PTK_BLOCK, 0, st>>>(S, iter, depth, n, d_n, hits, paths, valid, img); break;
+    case PTK_MODE_DIRECTLI: k_shade<PTK_MODE_DIRECTLI><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, depth, n, d_n, hits, paths, valid, img); break;
+    case PTK_MODE_MIS: k_shade<PTK_MODE_MIS><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, iter, depth, n, d_n, hits, paths, valid, img); break;
+    default: return PTK_E_BADARG;
+    }
+    return launch_rc();
 }
 
 int ptk_tonemap(const float* img, int res_x, int res_y, int iter, unsigned char* pbo, void* stream) {

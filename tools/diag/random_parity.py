@@ -66,7 +66,8 @@ def one_case(seed, tmp):
     pipeline = int(rng.choice([0, 0, 0, 10, 8, 1] if MESHES else [0, 0, 0, 10, 8]))
     iters = int(rng.integers(3, 13))
     s = ptk.Scene(path); o = orc.Scene(path)
-    kw = dict(in_flight=lanes, graph=graph, pipeline=pipeline)
+    tiles = int(rng.choice([1, 1, 2, 3])) if (lanes == 1 and pipeline in (0, 10) and part[0] == 1) else 1      # tiles in flight: only alone, on the fused launches
+    kw = dict(in_flight=lanes, graph=graph or tiles > 1, pipeline=pipeline, tiles=tiles)
     if part[0] > 1: kw.update(partition=part, spp=spp)
     r = ptk.Renderer(s, mode, **kw)
     planes = np.zeros((lanes, spp, o.P, 3), np.float32)
@@ -82,7 +83,7 @@ def one_case(seed, tmp):
     for p in flat[1:]: ref = ref + p
     img = r.image(); r.close(); s.close(); o.close()
     bad = int((img != ref).any(axis=1).sum())
-    return bad, info, dict(mode=mode, lanes=lanes, graph=graph, part=part, spp=spp, pipeline=pipeline, iters=iters, lit=float(ref.sum()))
+    return bad, info, dict(mode=mode, lanes=lanes, tiles=tiles, graph=graph, part=part, spp=spp, pipeline=pipeline, iters=iters, lit=float(ref.sum()))
 
 
 if __name__ == "__main__":
