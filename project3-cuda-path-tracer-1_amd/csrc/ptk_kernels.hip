@@ -386,7 +386,8 @@ __device__ __forceinline__ int gather_source(const Gather& G, int b, int i, int 
 // diag, materialid, pad} (dwords [2, 36) and 1 of DevGeom: the matrices stay 16-byte aligned); must be reached by all threads of the
 // block.  The launchers size the dynamic LDS with stage_bytes(S).
 extern __shared__ float4 ptk_dyn_lds[];
-__device__ __forceinline__ GeomStage stage_geoms(const SceneView& S) {
+// sync = false: the caller guarantees a workgroup barrier between this copy and the first read of gs.xf
+__device__ __forceinline__ GeomStage stage_geoms(const SceneView& S, bool sync = true) {
     GeomStage gs;
     gs.xf = reinterpret_cast<const float*>(ptk_dyn_lds);
     gs.on = S.lds_geoms > 0;
@@ -398,7 +399,7 @@ __device__ __forceinline__ GeomStage stage_geoms(const SceneView& S) {
             const int g = j / PTK_XF_FLOATS, k = j - g * PTK_XF_FLOATS;
             dst[j] = src[(size_t)g * (sizeof(DevGeom) / 4) + (k < 34 ? 2 + k : (k == 34 ? 1 : 0))];
         }
-        __syncthreads();
+        if (sync) __syncthreads();
     }
     return gs;
 }
@@ -1453,7 +1454,12 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         }
         return;
     }
-    const GeomStage gs = stage_geoms(S);                           // the trace phase always needs the primitives; MIS / DIRECT shading too
+    PTK_PHASE_BEGIN();
+    // the trace phase always needs the primitives; MIS / DIRECT shading too.  No barrier of its own (round 4: one barrier and one exposed load
+    // latency less at the head of every block): a shading launch publishes the copy with stage_materials' barrier, the camera launch with the
+    // first barrier of the trace phase — both come before the first read of gs.xf
+    const GeomStage gs = stage_geoms(S, false);
+    if (!GEN) PTK_PHASE(0);                          // 0: counts + primitive records -> LDS   (diagnostic build only, shading launches)
     // (round 4, measured and removed: an occupancy-sized grid whose blocks loop over the windows b, b + G, ... and stage the primitives once —
     // cornell 12.40 -> 8.74 Grays/s one iteration at a time, 23.17 -> 12.74 with three in flight, profiles/r4_ab_persistent_grid.txt: a resident
     // block that loops keeps its slot through every phase of its next window, where the dispatcher hands a finished block's slot to whichever
@@ -1508,10 +1514,13 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
         const int iter = (step - 1) * spp + 1;
         const int slot_off = slot_bias + cum_read(tail.cum_prev, cum_row(step, tail.ring_div, tail.cum_stride), depth);      // tiles in flight: the hits of this bounce in the bands above
-        const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
         // windows of the stream being read = ceil(paths the previous launch shaded / 256); the camera launch's stream (depth 0) is dense
         const int nw_prev = depth > 0 ? (d_n[-1] + NT - 1) / NT : (gen.n_pix * spp + NT - 1) / NT;
         int src_mine = 0, flag = 0, key = NKEY - 1, slot_mine = 0;
+        // (the window tables and the map word are loaded BEFORE the materials are staged: their two dependent round trips overlap the staging copy
+        // instead of following its barrier)
+        MatTable mt;
+        if (SPLIT) mt = stage_materials<NT, MATS>(S, s_mats);
         if (!SPLIT) {
             // HIT-DENSE shading: n and i count the paths of the previous launch that HIT something, in stream order — which is the reference's
             // compacted slot, the RNG key, itself.  A miss is never shaded (h.t <= 0: colour 0, no radiance, dead), so it is never even loaded: an
@@ -1531,6 +1540,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 src_mine = (w0 + k) * NT + (word & 0xff);
                 flag = 1; key = word >> 8; slot_mine = i + slot_off;
             }
+            mt = stage_materials<NT, MATS>(S, s_mats);
         } else {
             int hit_base = 0;
             src_mine = gather_source_w(io.pref, io.first, io.hit_pref, b, i, n, nw_prev, hit_base);      // 0 for i >= n
@@ -1561,6 +1571,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         s_perm[rank] = tid;
         s_slot[tid] = slot_mine;
         __syncthreads();
+        PTK_PHASE(0);                                // 1: materials -> LDS, window tables, map word, counting sort
         int src = -1;
         PathRegs p;
         p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
@@ -1599,6 +1610,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img, DEFER_NEE ? &rq : nullptr);
             if (DEFER_NEE && rq.on) s_anyreq = 1;
         }
+        PTK_PHASE(0);                                // 2: record loads + shading
         // survivor rank in the ORIGINAL (dense) order — the next bounce's compacted order, hence its RNG keys: every survivor sets the bit of
         // its original position in a 256-bit LDS mask, one barrier, rank = set bits below it (five barriers with a flag array + ballot before)
         if (alive) atomicOr(&s_alive[src >> 6], 1ull << (src & 63));
@@ -1629,6 +1641,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         }
     }
     __syncthreads();                           // shading tables are dead, s_ray is complete: the pair list may overwrite s_over
+    if (!GEN) PTK_PHASE(0);                          // 3: survivor ranks + path stores
     if (DEFER_NEE && s_anyreq) {               // block-uniform
         // ---- shadow phase (LightSampler::occulusionTest, lightSample.h:59-139) for the block's next-event samples.  Inside shade_path the
         // test is a per-lane candidate loop that runs max-over-lanes trips per wave and holds the shading state in registers meanwhile
@@ -1658,6 +1671,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         Analytic a;
         if (gs.on) analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
         else { a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0); if (active) analytic_closest(S, gs, ro, rd, a); }
+        if (!GEN) PTK_PHASE(0);                      // 4: (shadow phase +) closest hit: candidates, pair list, exact tests
         int flag = 0;
         bool heavy = false;
         const int slot = b * NT + tid;
@@ -1749,7 +1763,9 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     } else if (!COMPACT) {
         io.hr_nxt[b * NT + tid] = -2;
     }
+    if (!GEN && total > 0) PTK_PHASE(0);             // 5: hit record, inverse map, stores
     segments_tail2<NT>(tail, n, b, total, hits, io.agg_s, SPLIT ? nullptr : io.agg_h, cum_row(step, tail.ring_div, tail.cum_stride) + depth + 1);
+    if (!GEN && total > 0) { PTK_PHASE(0); PTK_PHASE_END(0); }      // 6: window counts + done counters (+ the last block's tables)
     }
 }
 
