@@ -596,9 +596,6 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_traverse(SceneView S, const unsig
 #ifndef PTK_WIDE_TOP
 #define PTK_WIDE_TOP 16
 #endif
-#ifndef PTK_WIDE_INLINE_LEAVES
-#define PTK_WIDE_INLINE_LEAVES 1  // leading leaf children tested at the node visit (0: pushed and popped like inner nodes, the round-3 walk; A/B)
-#endif
 #define PTK_WIDE_STACK 24         // stack entries per ray
 #define PTK_WIDE_STRIDE 25        // odd: the 16 rays of a wave spread over the LDS banks
 #define PTK_WIDE_LEAF 0x80000000u
@@ -614,13 +611,12 @@ __device__ __forceinline__ void wide_frame_selectors(bool px, bool py, bool pz, 
     f.selN = 0x0c000000u | (px ? 0u : 3u) | ((py ? 1u : 4u) << 8) | ((pz ? 2u : 5u) << 16);
     f.selF = 0x0c000000u | (px ? 3u : 0u) | ((py ? 4u : 1u) << 8) | ((pz ? 5u : 2u) << 16);
 }
-__device__ __forceinline__ bool wide_child_test(const uint4 c, const WideFrame& f, float t_min, float& tn_out) {
+__device__ __forceinline__ bool wide_child_test(const uint4 c, const WideFrame& f, float t_min) {
     const unsigned nb = __builtin_amdgcn_perm(c.y, c.x, f.selN), fb = __builtin_amdgcn_perm(c.y, c.x, f.selF);
     const float nx = (float)(nb & 0xffu), ny = (float)((nb >> 8) & 0xffu), nz = (float)((nb >> 16) & 0xffu);
     const float fx = (float)(fb & 0xffu), fy = (float)((fb >> 8) & 0xffu), fz = (float)((fb >> 16) & 0xffu);
     const float tn = fmaxf(fmaxf(__builtin_fmaf(nx, f.Ax, f.Bnx), __builtin_fmaf(ny, f.Ay, f.Bny)), __builtin_fmaf(nz, f.Az, f.Bnz));
     const float tf = fminf(fminf(__builtin_fmaf(fx, f.Ax, f.Bfx), __builtin_fmaf(fy, f.Ay, f.Bfy)), __builtin_fmaf(fz, f.Az, f.Bfz));
-    tn_out = tn;                                                  // (conservative near distance: the same test with a smaller t_min re-culls the child)
     return tn <= fminf(tf, t_min) && tf >= 0.f;
 }
 // the lanes of a pair / quad always run together (one ray, one control flow): values cross them through quad permutes
@@ -630,21 +626,6 @@ template <int LPR> __device__ __forceinline__ unsigned wide_group_or(unsigned v)
     v |= (unsigned)wide_x1((int)v);
     if (LPR == 4) v |= (unsigned)wide_x2((int)v);
     return v;
-}
-// exact leaf test against the cut t_cut (walk_apply's leaf branch on the leaf's own box, pathtrace.cu:249-267) WITHOUT the update: returns whether
-// the triangle is hit, and (tt, u, v)
-__device__ __forceinline__ bool wide_leaf_candidate(const uint4 l0, const uint4 l1, const uint4 l2, const uint4 l3, const WideRay& r, float t_cut, float& tt, float& u, float& v) {
-    DevNode nd;
-    nd.minx = __uint_as_float(l0.x); nd.miny = __uint_as_float(l0.y); nd.minz = __uint_as_float(l0.z);
-    nd.maxx = __uint_as_float(l0.w); nd.maxy = __uint_as_float(l1.x); nd.maxz = __uint_as_float(l1.y);
-    nd.a = 0; nd.b = 0;
-    float tEnter;
-    if (!aabb_test_fast(nd, r.o, r.inv, tEnter) || tEnter > t_cut) return false;
-    DevTriE T;
-    T.v0[0] = __uint_as_float(l1.z); T.v0[1] = __uint_as_float(l1.w); T.v0[2] = __uint_as_float(l2.x);
-    T.e1[0] = __uint_as_float(l2.y); T.e1[1] = __uint_as_float(l2.z); T.e1[2] = __uint_as_float(l2.w);
-    T.e2[0] = __uint_as_float(l3.x); T.e2[1] = __uint_as_float(l3.y); T.e2[2] = __uint_as_float(l3.z);
-    return tri_test(T, r.o, r.d, tt, u, v);
 }
 __device__ __forceinline__ unsigned wide_before(const uint4 c, int dir) {      // before[dir] of a child record
     const unsigned long long w = ((unsigned long long)c.z << 32) | c.y;
@@ -736,73 +717,23 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
                     f.Bnx = Bx - mx; f.Bfx = Bx + mx; f.Bny = By - my; f.Bfy = By + my; f.Bnz = Bz - mz; f.Bfz = Bz + mz;
                     const int nc = (int)(q0.w >> 24);
                     bool hit[NCH];
-                    float tnear[NCH];
-                    unsigned H = 0u;                              // hit children of this ray (bit = child index); bits 8-15 while exchanging: which of them are leaves
+                    unsigned H = 0u;                              // hit children of this ray (bit = child index)
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
-                        hit[k] = (q + LPR * k < nc) & wide_child_test(ch[k], f, r.t_min, tnear[k]);      // no short circuit: straight-line code
-                        if (LPR == 2 || LPR == 4) H |= hit[k] ? ((1u << (q + LPR * k)) | ((ch[k].w & PTK_WIDE_LEAF) ? (0x100u << (q + LPR * k)) : 0u)) : 0u;    // own bits; the group's lanes are ORed below
+                        hit[k] = (q + LPR * k < nc) & wide_child_test(ch[k], f, r.t_min);      // no short circuit: straight-line code
+                        if (LPR == 2 || LPR == 4) H |= hit[k] ? (1u << (q + LPR * k)) : 0u;    // own bits; the group's lanes are ORed below
                         else {
                             const unsigned long long bal = __ballot(hit[k]);
                             H |= ((unsigned)(bal >> qsh) & ((1u << LPR) - 1u)) << (LPR * k);
                         }
                     }
                     if (LPR == 2 || LPR == 4) H = wide_group_or<LPR>(H);
-#if PTK_WIDE_INLINE_LEAVES
-                    if (LPR == 2 || LPR == 4) {
-                        // LEADING LEAVES AT ONCE (round 4).  The hit children that come first in the ray's order and are leaves are tested HERE, each by
-                        // the lane that owns it, their records loaded together — instead of being pushed and popped one iteration each with all lanes
-                        // repeating the same test.  Sequential semantics (pathtrace.cu:249-267): leaf j is tested against the t_min its predecessors
-                        // left and wins on strict t_min > t — i.e. the winner is the smallest t, the earliest position among equal ones, and the
-                        // hit already held wins a tie; a leaf cut against the OLDER t_min here would be cut or lose there.  The remaining children
-                        // are culled again with the new t_min before they are pushed.  (CPU model, tools/diag/wide_sim.cpp: iterations per listed
-                        // ray 9.7 -> 7.4, the slowest ray of a launch 70-90 -> 45-50: the walk's duration is that ray's chain.)
-                        const unsigned LM = (H >> 8) & 0xffu;
-                        H &= 0xffu;
-                        unsigned IN = 0u;
-#pragma unroll
-                        for (int k = 0; k < NCH; ++k)
-                            IN |= (hit[k] && (ch[k].w & PTK_WIDE_LEAF) && ((H & wide_before(ch[k], r.dir) & ~LM) == 0u)) ? (1u << (q + LPR * k)) : 0u;
-                        const unsigned INg = wide_group_or<LPR>(IN);
-                        if (INg) {
-                            float bt = r.t_min, bu = 0.f, bv = 0.f; int bpos = -1, btri = -1;
-#pragma unroll
-                            for (int k = 0; k < NCH; ++k) {
-                                if (IN & (1u << (q + LPR * k))) {
-                                    const uint4* lp = S.wleaves + (size_t)(ch[k].w & ~PTK_WIDE_LEAF) * 4;
-                                    const uint4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
-                                    float tt, u, v;
-                                    if (wide_leaf_candidate(l0, l1, l2, l3, r, r.t_min, tt, u, v)) {
-                                        const int pos = __popc(H & wide_before(ch[k], r.dir));
-                                        if (bt > tt || (bt == tt && bpos >= 0 && pos < bpos)) { bt = tt; bpos = pos; btri = (int)l3.w; bu = u; bv = v; }
-                                    }
-                                }
-                            }
-                            // the group's winner: butterfly over the lanes (smaller t; equal t: the earlier position, -1 = the hit already held)
-                            {
-                                const float ot = __int_as_float(wide_x1(__float_as_int(bt))); const int op = wide_x1(bpos), otr = wide_x1(btri);
-                                const float ou = __int_as_float(wide_x1(__float_as_int(bu))), ov = __int_as_float(wide_x1(__float_as_int(bv)));
-                                if (ot < bt || (ot == bt && op < bpos)) { bt = ot; bpos = op; btri = otr; bu = ou; bv = ov; }
-                            }
-                            if (LPR == 4) {
-                                const float ot = __int_as_float(wide_x2(__float_as_int(bt))); const int op = wide_x2(bpos), otr = wide_x2(btri);
-                                const float ou = __int_as_float(wide_x2(__float_as_int(bu))), ov = __int_as_float(wide_x2(__float_as_int(bv)));
-                                if (ot < bt || (ot == bt && op < bpos)) { bt = ot; bpos = op; btri = otr; bu = ou; bv = ov; }
-                            }
-                            if (bpos >= 0) { r.t_min = bt; r.tri = btri; r.u = bu; r.v = bv; }
-                            if (STATS) nt += (q == 0) ? __popc(INg) : 0;
-                            unsigned R = 0u;
-#pragma unroll
-                            for (int k = 0; k < NCH; ++k) {
-                                hit[k] = hit[k] && !(IN & (1u << (q + LPR * k))) && (tnear[k] <= r.t_min);
-                                R |= hit[k] ? (1u << (q + LPR * k)) : 0u;
-                            }
-                            H = wide_group_or<LPR>(R);
-                        }
-                    }
-#else
-                    H &= 0xffu;
-#endif
+                    // (round 4, measured and removed — commit "leading leaf children tested at the node visit": the hit children that come first in the
+                    // ray's order and are leaves tested at once, each by the lane that owns it, the rest culled again with the new t_min.  Bit-exact;
+                    // the CPU model (tools/diag/wide_sim.cpp: wide_sim_inline) counts 7.4 instead of 9.7 loop iterations per listed ray and 45-50 instead
+                    // of 70-90 for the slowest ray — but k_traverse_wide went from 75.2 to 78.1 us and the bunny scene from 5.85 to 5.34 Grays/s
+                    // (profiles/r4_ab_inline_leaves.txt): a node visit with leaves is then TWO dependent fetches (node, then its leaves), so the chain of
+                    // dependent round trips of a ray shrinks by ~11 %, not by the iteration count, and the walk pays 78 instead of 64 VGPRs for it.)
                     const int nh = __popc(H);
                     if (sp + nh > PTK_WIDE_STACK) { threaded = true; break; }
                     // all hit children at once, in reverse visiting order: the child visited first ends on top
