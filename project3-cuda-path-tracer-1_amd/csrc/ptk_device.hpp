@@ -1158,7 +1158,7 @@ struct LightRec { f3 pos, emit; float pdf; bool is_zero; };
 // as unoccluded; the caller stores the contribution it WOULD add in `contrib` and adds it after the block's shadow phase if the ray is free.
 // The ray itself is parked in the caller's LDS slot at once — (origin, minT), (direction, pixel) — so that it is not held in registers while the
 // BSDF of the sample is evaluated.
-struct ShadowReq { bool on; float4* slot; int pix; f3 contrib; };
+struct ShadowReq { bool on; float4* slot; int dstride; int pix; f3 contrib; };      // slot[0] = (origin, minT), slot[dstride] = (direction, pixel)
 
 // LightSampler::lightPDF, lightSample.h:141-169
 // Opt-in "fixed" cube lights (ptk_set_light_fix; NOT reference behaviour): world-space areas of the three face
@@ -1275,7 +1275,7 @@ PTK_DI void light_sample(const SceneView& S, const GeomStage& gs, const DevMater
     if (defer) {
         const f3 ori = viewPos + 1e-5f * rayDir;
         defer->slot[0] = make_float4(ori.x, ori.y, ori.z, length(lightPos - ori));
-        defer->slot[1] = make_float4(rayDir.x, rayDir.y, rayDir.z, __int_as_float(defer->pix));
+        defer->slot[defer->dstride] = make_float4(rayDir.x, rayDir.y, rayDir.z, __int_as_float(defer->pix));
         defer->on = true;
     } else if (occluded(S, gs, viewPos + 1e-5f * rayDir, rayDir, lightPos)) { rec.emit = mk3(0, 0, 0); rec.pdf = -1.f; return; }
     const DevMaterial& lm = mats[geom.materialid];

@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
 // point and the deferred normal for it (a later round can only lower the key, and then overwrites).
 // LDS the block-cooperative closest-hit search works in (24.1 KB for 256 threads)
 struct TraceLds {
-    float4* ray;                 // [2 * NT]  origin, direction of the block's rays
+    float4* ray;                 // [2 * NT]  origins [0, NT), directions [NT, 2 NT) of the block's rays: two planes, so that the 16-byte reads of the pair
+                                 //           list's lanes (neighbouring rays) fall on neighbouring 16-byte slots — interleaved (origin, direction) pairs put eight
+                                 //           lanes on two LDS rows (round 3's counters: 25 % of the LDS cycles of k_shade_trace were bank conflicts)
     float2* res;                 // [3 * NT]  winner's hit point + deferred normal, 24 B per ray (with 32 B the block's static LDS crosses
                                  //           160 KB / 6: five blocks per CU instead of six)
     unsigned long long* best;    // [NT]
@@ -191,8 +193,8 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
     float4* s_ray = L.ray; float2* s_res = L.res; unsigned long long* s_best = L.best; unsigned short* s_list = L.list; int* s_cnt = L.cnt;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (!RAYS_IN_LDS) {
-        s_ray[2 * tid] = make_float4(ro.x, ro.y, ro.z, 0.f);
-        s_ray[2 * tid + 1] = make_float4(rd.x, rd.y, rd.z, 0.f);
+        s_ray[tid] = make_float4(ro.x, ro.y, ro.z, 0.f);
+        s_ray[NT + tid] = make_float4(rd.x, rd.y, rd.z, 0.f);
     }
     s_best[tid] = ~0ull;
     for (int base = 0; base < S.n_geoms; base += 32) {
@@ -238,7 +240,7 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
                     const unsigned e = s_list[pi];
                     r = (int)(e & ((1u << RB) - 1u));
                     const int k = (int)(e >> RB);
-                    const float4 o4 = s_ray[2 * r], d4 = s_ray[2 * r + 1];
+                    const float4 o4 = s_ray[r], d4 = s_ray[NT + r];
                     const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
                     const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
 #ifdef PTK_DIAG_DOUBLE_TEST      // timing experiments only
@@ -275,7 +277,7 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
 // them), thread j tests pairs j, j + NT, ... and ORs the reference's occlusion condition into the ray's bit of a 256-bit LDS mask.  The
 // result is a boolean OR over the primitives — order-independent, and the primitives the candidate test culls provably miss (returns 0,
 // tests/test_candidate_margin.py) — so it equals the per-lane loop of occluded_analytic.  All NT threads must call it; ends with a barrier.
-//   L.ray[2 r] = (origin, minT), L.ray[2 r + 1] = (direction, -) of shadow ray r, written by thread r before the caller's last barrier.
+//   L.ray[r] = (origin, minT), L.ray[NT + r] = (direction, -) of shadow ray r, written by thread r before the caller's last barrier.
 template <int NT, int LP>
 __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, unsigned long long* s_occ, bool active, f3 ro, f3 rd) {
     constexpr int NW = NT / 64;
@@ -314,7 +316,7 @@ __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const Ge
                     const unsigned e = s_list[pi];
                     const int r = (int)(e & ((1u << RB) - 1u));
                     const int k = (int)(e >> RB);
-                    const float4 o4 = s_ray[2 * r], d4 = s_ray[2 * r + 1];
+                    const float4 o4 = s_ray[r], d4 = s_ray[NT + r];
                     const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
                     const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
                     const float minT = o4.w;
@@ -1484,7 +1486,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     int total = 0;                         // survivors of the block
     // shadow ray of thread t -> slots 2t, 2t + 1 of the (still idle) upper half of the trace phase's LDS: s_res / s_best are first written
     // inside analytic_closest_lds
-    ShadowReq rq; rq.on = false; rq.slot = s_stage + 2 * NT + 2 * tid; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
+    ShadowReq rq; rq.on = false; rq.slot = s_stage + 2 * NT + tid; rq.dstride = NT; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
     int gen_pixw = 0;                      // GEN + COMPACT: the camera ray's pixel word, stored with the path state after the trace phase
     // ... when the scene is open (gen.late_stores: the host saw fewer than ~half of the camera rays of earlier iterations hit something);
     // otherwise before it, where the stores overlap the tracing (cornell.txt: 22.8 vs 22.6 Grays/s).  Same values either way.  (Deciding here
@@ -1519,8 +1521,8 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 st4(io.nxt.d_bnc, i, make_float4(d.x, d.y, d.z, __int_as_float(gen.trace_depth)));
                 st4(io.nxt.col_pdf, i, make_float4(1.f, 1.f, 1.f, -1.f));
             }
-            s_ray[2 * tid] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
-            s_ray[2 * tid + 1] = make_float4(d.x, d.y, d.z, 0.f);
+            s_ray[tid] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
+            s_ray[NT + tid] = make_float4(d.x, d.y, d.z, 0.f);
         }
     } else {
         // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
@@ -1648,8 +1650,8 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
                 st4(io.nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
             }
-            s_ray[2 * my_rank] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix));          // hand the new ray to the thread that traces it
-            s_ray[2 * my_rank + 1] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces));
+            s_ray[my_rank] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix));          // hand the new ray to the thread that traces it
+            s_ray[NT + my_rank] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces));
         }
     }
     __syncthreads();                           // shading tables are dead, s_ray is complete: the pair list may overwrite s_over
@@ -1661,7 +1663,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         const TraceLds Lsh = {s_stage + 2 * NT, nullptr, nullptr, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
         bool occ = false;
         f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0); float s_minT = 0.f; int s_pix = 0;
-        if (rq.on) { const float4 o4 = rq.slot[0], d4 = rq.slot[1]; so = mk3(o4.x, o4.y, o4.z); s_minT = o4.w; sd = mk3(d4.x, d4.y, d4.z); s_pix = __float_as_int(d4.w); }
+        if (rq.on) { const float4 o4 = rq.slot[0], d4 = rq.slot[NT]; so = mk3(o4.x, o4.y, o4.z); s_minT = o4.w; sd = mk3(d4.x, d4.y, d4.z); s_pix = __float_as_int(d4.w); }
         if (gs.on) {
             analytic_anyhit_lds<NT, LP>(S, gs, Lsh, s_occ, rq.on, so, sd);
             occ = (s_occ[tid >> 6] >> (tid & 63)) & 1ull;
@@ -1678,7 +1680,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         const bool active = tid < total;
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
         if (active) {
-            const float4 o4 = s_ray[2 * tid], d4 = s_ray[2 * tid + 1]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+            const float4 o4 = s_ray[tid], d4 = s_ray[NT + tid]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
         }
         Analytic a;
         if (gs.on) analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
