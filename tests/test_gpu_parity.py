@@ -770,6 +770,7 @@ FULL = [  # BASELINE.json configs at full size (oracle: a few seconds per iterat
     ("sphere.txt", None, -1, "MIS", 1),               # at the file's own 800x800 depth 8
     ("disney_test.txt", None, -1, "BSDF", 1),
     ("obj_test.txt", None, -1, "MIS", 2),             # configs[2] as shipped (12 triangles, no light): the fused kernel with the reference walk in its trace phase
+    ("obj_test.txt", (2048, 2048), 16, "MIS", 1),     # configs[4]'s scene file AS SHIPPED at 2048 x 2048 depth 16 (its timed substitute: test_configs4_tile_part_full_size)
 ]
 
 
@@ -780,11 +781,15 @@ def test_full_size_configs(ptk, orc, torch_cuda, name, res, depth, mode, iters):
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, m)
     ref = np.zeros((o.P, 3), np.float32)
-    for it in range(1, iters + 1):
-        r.iterate(it)
-        _, live = o.pathtrace(m, it, ref)
-        counts, _ = r.live_counts()
-        assert np.array_equal(counts, live), (counts, live)
+    orc.set_threads(host_threads())               # (the oracle's per-path loops over OpenMP threads: identical results, tests/test_oracle_pins.py)
+    try:
+        for it in range(1, iters + 1):
+            r.iterate(it)
+            _, live = o.pathtrace(m, it, ref)
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, live), (counts, live)
+    finally:
+        orc.set_threads(1)
     img = r.image(); r.close()
     bad = (img != ref).any(axis=1)
     assert not bad.any(), f"{int(bad.sum())} of {len(ref)} pixels differ"

@@ -1,4 +1,4 @@
-"""Aggregates the PMC passes of tools/refresh_profiles.sh into profiles/r3_pmc.json: per-launch HBM traffic of the kernels of
+"""Aggregates the PMC passes of tools/refresh_profiles.sh into profiles/<round>_pmc.json: per-launch HBM traffic of the kernels of
 the intersect stage (bench.py's roofline.traffic / achieved_hbm) and the SQ counter table (VALU instructions and busy
 fraction, wave occupancy, LDS) bench.py cites as roofline.counters.
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM /
