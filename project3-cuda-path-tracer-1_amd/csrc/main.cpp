@@ -7,7 +7,7 @@
 // binary PPM (P6) and the raw float32 radiance sum (.f32).
 //
 // usage: ptk_headless SCENE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]
-//        [--warmup W] [--no-save] [--in-flight L] [--graph 0|1] [--eager]
+//        [--warmup W] [--no-save] [--in-flight L] [--tiles K] [--graph 0|1] [--eager]
 // Timing (bench.py `cpp_api`): --warmup W renders W untimed iterations first (then waits for the GPU); the timed region is the remaining
 // pathtrace() calls plus ONE pathtraceResolve() — what a viewer that saves the image at the end pays.  --eager resolves after every call
 // (the reference's pathtrace.cu:809-810 behaviour), --in-flight / --graph are the ptk_set_* knobs (defaults 1 / 0: the reference's order).
@@ -94,7 +94,7 @@ static void saveImage(const Scene& scene, int iteration, const std::string& base
 
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("Usage: %s SCENEFILE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]\n", argv[0]); return 1; }
-    int iters = -1, rw = -1, rh = -1, depth = -1, warmup = 0, in_flight = 0, graph = -1;
+    int iters = -1, rw = -1, rh = -1, depth = -1, warmup = 0, in_flight = 0, graph = -1, tiles = 0;
     bool save = true, eager = false;
     std::string out;
     for (int i = 2; i < argc; ++i) {
@@ -107,6 +107,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--in-flight") && i + 1 < argc) in_flight = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--graph") && i + 1 < argc) graph = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--tiles") && i + 1 < argc) tiles = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--no-save")) save = false;
         else if (!std::strcmp(argv[i], "--eager")) eager = true;
     }
@@ -127,6 +128,7 @@ int main(int argc, char** argv) {
     if (out.empty()) out = scene->state.imageName.empty() ? std::string("render") : scene->state.imageName;
 
     if (in_flight > 0 && ptk_set_iterations_in_flight(in_flight)) { std::printf("bad --in-flight\n"); return 5; }
+    if (tiles > 0 && ptk_set_tiles_in_flight(tiles)) { std::printf("bad --tiles\n"); return 5; }
     if (graph >= 0) ptk_set_graph_replay(graph);
     int iteration = 0;
     auto t0 = std::chrono::steady_clock::now();

@@ -819,12 +819,14 @@ int ptk_timer_stop(float* ms) {
 void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
 // Knobs of the C++ API, read at pathtraceInit (the four reference signatures have no room for them): PTK_IN_FLIGHT=<L> iterations in flight,
-// PTK_GRAPH=1 hipGraph replay (both as ptk_set_*; defaults 1 / 0 = the reference's accumulation order), PTK_EAGER_IMAGE=1 = refresh
+// PTK_TILES=<K> tiles in flight (bit-identical image; wants PTK_GRAPH=1), PTK_GRAPH=1 hipGraph replay (all as ptk_set_*; defaults 1 / 1 / 0 = the
+// reference's accumulation order), PTK_EAGER_IMAGE=1 = refresh
 // scene->state.image after EVERY call like pathtrace.cu:809-810 (a 7.7 MB D2H and a host wait per 0.3 ms iteration at 800 x 800).
 void pathtraceInit(Scene* scene) {
     if (!g.live) {
         if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.n_lanes = l; }
         if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;
+        if (const char* e = getenv("PTK_TILES")) { const int t = atoi(e); if (t >= 1 && t <= kMaxLanes) g.want_tiles = t; }
     }
     PTK_CHECK("pathtraceInit", context_init(scene));
     g.eager_image = getenv("PTK_EAGER_IMAGE") && atoi(getenv("PTK_EAGER_IMAGE")) != 0;
