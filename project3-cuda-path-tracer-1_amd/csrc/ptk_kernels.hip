@@ -736,6 +736,10 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
                     // of 70-90 for the slowest ray — but k_traverse_wide went from 75.2 to 78.1 us and the bunny scene from 5.85 to 5.34 Grays/s
                     // (profiles/r4_ab_inline_leaves.txt): a node visit with leaves is then TWO dependent fetches (node, then its leaves), so the chain of
                     // dependent round trips of a ray shrinks by ~11 %, not by the iteration count, and the walk pays 78 instead of 64 VGPRs for it.)
+                    // (round 4, measured and removed as well — LEAF CLUSTERS: references to all-leaf nodes replaced by "n consecutive leaf records", all
+                    // tested at once by the group's lanes without the node fetch, the ordered replay kept for the rare visit with two candidates.
+                    // Bit-exact; model chain 9.7 -> 7.7 round trips per ray; one iteration in flight +3 %, three in flight -5.5 %
+                    // (profiles/r4_ab_leaf_clusters.txt): n x 64 B and n exact tests per visit instead of 144 B + the ~1.5 leaves the ray meets.)
                     const int nh = __popc(H);
                     if (sp + nh > PTK_WIDE_STACK) { threaded = true; break; }
                     // all hit children at once, in reverse visiting order: the child visited first ends on top

@@ -197,3 +197,83 @@ extern "C" void wide_sim_inline(const uint32_t* nodes, const float* leaves, int 
         node_visits[r] = nv; leaf_visits[r] = nl; inl[r] = ni;
     }
 }
+
+// variant (round 4, idea "leaf clusters"): a node whose children are ALL leaves is not fetched at all — the parent's reference names its leaves
+// (consecutive records), which are fetched together and tested in parallel over the group's lanes.  trips = dependent round trips of the ray:
+// inner-node visits + cluster visits (one each) + single leaves popped from mixed nodes.  cl = cluster visits, cl_leaves = leaves tested in them.
+extern "C" void wide_sim_clusters(const uint32_t* nodes, const float* leaves, int n_rays, const float* o, const float* d,
+                                  const float* tmin_init, int* trips_out, int* cl_out, int* cl_leaves_out) {
+    auto leaf_test = [&](const float* L, const float* ro, const float* rd, const double* inv, float& t_min) {
+        double tn = -DBL_MAX, tf = DBL_MAX;
+        for (int a = 0; a < 3; ++a) {
+            double t0 = ((double)L[a] - ro[a]) * inv[a], t1 = ((double)L[3 + a] - ro[a]) * inv[a];
+            if (t0 > t1) { const double t = t0; t0 = t1; t1 = t; }
+            tn = tn > t0 ? tn : t0; tf = tf < t1 ? tf : t1;
+        }
+        if (tn <= tf && tf > 0 && !(tn > t_min)) {
+            const float* v0 = L + 6; const float* e1 = L + 9; const float* e2 = L + 12;
+            const double px = rd[1] * e2[2] - rd[2] * e2[1], py = rd[2] * e2[0] - rd[0] * e2[2], pz = rd[0] * e2[1] - rd[1] * e2[0];
+            const double det = e1[0] * px + e1[1] * py + e1[2] * pz;
+            if (det != 0) {
+                const double id = 1.0 / det, sx = ro[0] - v0[0], sy = ro[1] - v0[1], sz = ro[2] - v0[2];
+                const double u = (sx * px + sy * py + sz * pz) * id;
+                const double qx = sy * e1[2] - sz * e1[1], qy = sz * e1[0] - sx * e1[2], qz = sx * e1[1] - sy * e1[0];
+                const double v = (rd[0] * qx + rd[1] * qy + rd[2] * qz) * id, t = (e2[0] * qx + e2[1] * qy + e2[2] * qz) * id;
+                if (!(t < 0 || u < 0 || v < 0 || 1 - u - v < 0) && t_min > t) t_min = (float)t;
+            }
+        }
+    };
+    auto all_leaves = [&](uint32_t ni) { const uint32_t* nd = nodes + 36 * (size_t)ni; const int nc = (int)(nd[3] >> 24); for (int c = 0; c < nc; ++c) if (!(nd[4 + 4 * c + 3] & 0x80000000u)) return false; return true; };
+    for (int r = 0; r < n_rays; ++r) {
+        const float* ro = o + 3 * r; const float* rd = d + 3 * r;
+        const double inv[3] = {1.0 / rd[0], 1.0 / rd[1], 1.0 / rd[2]};
+        float t_min = tmin_init[r];
+        const int dir = mtbvh_dir(rd);
+        uint32_t stk[64]; int sp = 0; uint32_t cur = 0; int trips = 0, ncl = 0, nll = 0;
+        for (;;) {
+            ++trips;
+            if (!(cur & 0x80000000u)) {
+                const uint32_t* nd = nodes + 36 * (size_t)cur;
+                const int nc = (int)(nd[3] >> 24);
+                if (cur != 0 && all_leaves(cur)) {                 // cluster: every leaf fetched and tested, no child-box tests
+                    ++ncl; nll += nc;
+                    int order[8];
+                    for (int c = 0; c < nc; ++c) order[c] = c;
+                    uint32_t bef[8];
+                    for (int c = 0; c < nc; ++c) { const uint32_t* w = nd + 4 + 4 * c; const uint64_t ww = ((uint64_t)w[2] << 32) | w[1]; bef[c] = (uint32_t)(ww >> (16 + 8 * dir)) & 255u; }
+                    for (int a = 0; a < nc; ++a) for (int b2 = a + 1; b2 < nc; ++b2)
+                        if (__builtin_popcount(bef[order[b2]]) < __builtin_popcount(bef[order[a]])) { const int t = order[a]; order[a] = order[b2]; order[b2] = t; }
+                    for (int a = 0; a < nc; ++a) leaf_test(leaves + 16 * (size_t)(nd[4 + 4 * order[a] + 3] & 0x7fffffffu), ro, rd, inv, t_min);
+                } else {
+                    float p[3]; std::memcpy(p, nd, 12);
+                    double sc[3];
+                    for (int a = 0; a < 3; ++a) { uint32_t e = ((nd[3] >> (8 * a)) & 255u) << 23; float f; std::memcpy(&f, &e, 4); sc[a] = f; }
+                    uint32_t H = 0; uint32_t before[8]; uint32_t ref[8];
+                    for (int c = 0; c < nc; ++c) {
+                        const uint32_t* w = nd + 4 + 4 * c;
+                        const int qlo[3] = {(int)(w[0] & 255), (int)((w[0] >> 8) & 255), (int)((w[0] >> 16) & 255)};
+                        const int qhi[3] = {(int)(w[0] >> 24), (int)(w[1] & 255), (int)((w[1] >> 8) & 255)};
+                        const uint64_t ww = ((uint64_t)w[2] << 32) | w[1];
+                        before[c] = (uint32_t)(ww >> (16 + 8 * dir)) & 255u; ref[c] = w[3];
+                        double tn = -DBL_MAX, tf = DBL_MAX;
+                        for (int a = 0; a < 3; ++a) {
+                            const double lo = p[a] + qlo[a] * sc[a], hi = p[a] + qhi[a] * sc[a];
+                            double t0 = (lo - ro[a]) * inv[a], t1 = (hi - ro[a]) * inv[a];
+                            if (t0 > t1) { const double t = t0; t0 = t1; t1 = t; }
+                            tn = tn > t0 ? tn : t0; tf = tf < t1 ? tf : t1;
+                        }
+                        if (tn <= (tf < t_min ? tf : t_min) && tf >= 0) H |= 1u << c;
+                    }
+                    const int nh = __builtin_popcount(H);
+                    for (int c = 0; c < nc; ++c) if (H & (1u << c)) stk[sp + nh - 1 - __builtin_popcount(H & before[c])] = ref[c];
+                    sp += nh;
+                }
+            } else {
+                leaf_test(leaves + 16 * (size_t)(cur & 0x7fffffffu), ro, rd, inv, t_min);
+            }
+            if (sp == 0) break;
+            cur = stk[--sp];
+        }
+        trips_out[r] = trips; cl_out[r] = ncl; cl_leaves_out[r] = nll;
+    }
+}
