@@ -1,7 +1,7 @@
 """A/B on the GPU box over ENVIRONMENT settings (one child process per measurement, alternating runs): Grays/s of (scene, mode, lanes, ...)
 cases for several `VAR=value,VAR=value` settings.
 usage: ab_env.py "<setting>;<setting>..." "<case>;<case>..." [reps]   setting = "-" (nothing) or VAR=v[,VAR=v...];
-       case = scene,mode[,lanes[,pipeline[,W,H[,depth]]]]"""
+       case = scene,mode[,lanes[,pipeline[,W,H[,depth[,tiles]]]]]  (W = 0: the scene's own size)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
@@ -10,9 +10,9 @@ sys.path.insert(0, %r)
 ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
 a = sys.argv[1].split(",")
 scn, mode = a[0], int(a[1]); lanes = int(a[2]) if len(a) > 2 else 3; pipe = int(a[3]) if len(a) > 3 else 0
-res = (int(a[4]), int(a[5])) if len(a) > 5 else None; depth = int(a[6]) if len(a) > 6 else -1
+res = (int(a[4]), int(a[5])) if len(a) > 5 and int(a[4]) > 0 else None; depth = int(a[6]) if len(a) > 6 else -1; tiles = int(a[7]) if len(a) > 7 else 1
 s = ptk.Scene(os.path.join(%r, "scenes", scn), res=res, depth=depth)
-r = ptk.Renderer(s, mode, pipeline=pipe, in_flight=lanes, graph=lanes > 1)
+r = ptk.Renderer(s, mode, pipeline=pipe, in_flight=lanes, graph=lanes > 1 or tiles > 1, tiles=tiles)
 n = 96 if s.width * s.height <= 1000000 else 32
 for it in range(1, 33): r.iterate(it)
 r.sync(); r0 = r.ray_total(); r.timer_start()
