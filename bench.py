@@ -494,8 +494,9 @@ def main():
                                                mrays_per_s=round(brays / bms / 1e3, 1))
         ref_order = None
         if N == 1 and not a.lean and (a.in_flight != 1 or a.graph):
-            # the reference's own schedule: one iteration at a time, eager launches -> its float accumulation order exactly
-            # (the headline overlaps `in_flight` iterations: image = ((p0 + p1) + p2), each iteration itself unchanged)
+            # the reference's own schedule: one iteration at a time, eager launches.  (The headline overlaps `in_flight` iterations, each computed
+            # unchanged into its own plane and folded into the image in iteration order: in BSDF / DIRECT mode — this workload — the image is
+            # bit-identical to this schedule's, tests/test_gpu_parity.py::test_iterations_in_flight_keep_the_reference_order; MIS: float association differs)
             rr = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=1, graph=False)
             for i in range(1, a.warmup * IPS + 1):
                 rr.iterate(i)
@@ -518,6 +519,19 @@ def main():
             rt.close()
             ref_order["tiles_in_flight"] = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
                                             "config": "tiles_in_flight 3, graph_replay true: the reference's accumulation order and RNG keys, bit-identical image (tests/test_gpu_parity.py::test_tiles_in_flight*)"}
+        if ref_order is not None and a.tiles <= 1 and a.in_flight > 1 and a.mode != "mis":
+            # what the ordered accumulation costs: the headline's configuration with planes that accumulate instead (ptk_set_ordered_accumulation(0):
+            # image = ((p0 + p1) + p2), float association differs from the reference's) — rounds 2 and 3 timed THIS form
+            ru = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), ordered=0)
+            for i in range(1, a.warmup * IPS + 1):
+                ru.iterate(i)
+            ru.sync(); q0 = ru.ray_total(); tt0 = time.perf_counter()
+            for i in range(a.warmup * IPS + 1, (a.warmup + a.steps) * IPS + 1):
+                ru.iterate(i)
+            ru.sync(); tt = time.perf_counter() - tt0; qr = ru.ray_total() - q0
+            ru.close()
+            ref_order["accumulating_planes"] = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
+                                                "config": f"iterations_in_flight {a.in_flight}, graph_replay {bool(a.graph)}, ptk_set_ordered_accumulation(0): the form rounds 2-3 timed; image = ((p0 + p1) + p2), NOT the reference's association"}
         cpp_api = None
         exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
         if N == 1 and not a.lean and os.path.exists(exe):
@@ -578,6 +592,10 @@ def main():
                                                           + ", one RCCL reduce(SUM) of the float32[3*W*H] radiance buffer in the timed region"),
                        "iterations_total": head["calls"] * (N if a.shard == "iterations" else 1) * spp,
                        "iterations_in_flight": a.in_flight if a.tiles <= 1 else 1, "tiles_in_flight": max(a.tiles, 1), "graph_replay": bool(a.graph),
+                       "accumulation": ("in place: the reference's own order" if (a.in_flight <= 1 and spp <= 1) or a.tiles > 1 else
+                                        ("ordered: every iteration's plane is folded into the image in iteration order (one k_merge_planes launch per iteration, inside the "
+                                         "timed region); BSDF / DIRECT add once per pixel and iteration: the image is bit-identical to one iteration at a time (reference_order)")
+                                        if a.mode != "mis" else "planes accumulate (MIS adds bounce by bounce: no order of whole iterations is bit-identical), summed when the image is read"),
                        "pipeline": ("one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d (segmented streams, physical-slot hit records, window hit "
                                     "prefixes); device-resident counts, no host sync") if fused else
                                    "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync",

@@ -169,15 +169,25 @@ int ptk_get_sample_mode(void);
  * order and every path keeps the reference's RNG key (pathtrace.cu:458,532: a band's compacted slots continue those of the bands above it): the
  * image is BIT-IDENTICAL to the default's, i.e. to the reference's own accumulation order (pathtrace.cu:697-810). */
 int ptk_set_tiles_in_flight(int tiles);
-/* Iterations in flight (1..16, default 1; set before ptk_pathtrace_init).  With L > 1, iteration `it` runs on lane
- * (it-1) % L (own stream, buffers and radiance plane), so consecutive ptk_pathtrace calls overlap on the GPU.  Every
- * iteration is computed exactly as with L = 1; only the order of the per-pixel additions changes: plane l sums
- * iterations l+1, l+1+L, ... and the image is ((plane0 + plane1) + plane2) + ...  Not a reference feature. */
+/* Iterations in flight (1..16, default 1; set before ptk_pathtrace_init).  With L > 1, the call `step` runs on lane
+ * (step-1) % L (own stream, buffers and radiance plane), so consecutive ptk_pathtrace calls overlap on the GPU.  Every
+ * iteration is computed exactly as with L = 1 into its lane's plane — zero when it starts — and the plane is folded into the
+ * image when the iteration is done, IN CALL ORDER (ordered accumulation): image = ((image + it_1) + it_2) + ..., the
+ * reference's running sum (pathtrace.cu:600).  BSDF and DIRECT add at most once per pixel and iteration (pathtrace.cu:398,486,
+ * 303-311), so there the image is BIT-IDENTICAL to one iteration at a time; MIS adds its next-event terms bounce by bounce
+ * (pathtrace.cu:556,572): no order of whole iterations reproduces that sum, so by default MIS keeps the cheaper form
+ * (ptk_set_ordered_accumulation below; use ptk_set_tiles_in_flight for a bit-identical MIS image).  Not a reference feature. */
 int ptk_set_iterations_in_flight(int lanes);
+/* Accumulation policy with several radiance planes (L iterations in flight and / or S samples per launch; set before ptk_pathtrace_init).
+ * 1: ordered, as described above (one small merge launch per call; measured -3 % on cornell.txt BSDF, -9 % on mis_test.txt 1024 x 1024).
+ * 0: the planes accumulate — plane l sums the calls l+1, l+1+L, ... — and are summed when the image is read: ((plane0 + plane1) + plane2) + ...
+ * -1 (default): ordered unless the sample mode at ptk_pathtrace_init is MIS, where no order makes the image bit-identical. */
+int ptk_set_ordered_accumulation(int on);
 /* Samples per launch (1..64, default 1; set before ptk_pathtrace_init).  With spp > 1, ptk_pathtrace(.., step) traces
  * iterations (step-1)*spp + 1 .. step*spp of the owned pixels in one set of launches: camera jitter is keyed per iteration
  * as usual, the shading RNG by (first iteration of the batch, compacted slot, depth), and every sample accumulates into its
- * own radiance plane; the image is the sum of the planes in order.  Used with the tile partition so that a rank that owns
+ * own radiance plane, folded into the image in sample order when the launch is done or summed when the image is read
+ * (ptk_set_ordered_accumulation).  Used with the tile partition so that a rank that owns
  * 1/N of the pixels still launches full-size kernels (multi-GPU weak scaling).  Not a reference feature. */
 int ptk_set_samples_per_launch(int spp);
 /* Opt-in "fixed" cube lights.  The reference's LightSampler gives cube lights neither a sampled position nor a
@@ -209,8 +219,9 @@ int ptk_set_tile_partition(int n_parts, int part, int tile_rows);
 /* Iteration sharding — the exact multi-GPU validation mode of SURVEY §8e (set before ptk_pathtrace_init; (1,0) = off).
  * ptk_pathtrace(.., step) then renders iteration (step-1)*n_shards + shard + 1 of the WHOLE frame, with the reference's own
  * RNG keys (camera: (x, y, iter), pathtrace.cu:148 — shading: (iter, compacted slot, depth), pathtrace.cu:458,532), so shard g
- * of n computes exactly the iterations g+1, g+1+n, ... of a single-GPU render: its radiance buffer is plane g of a single
- * process with n iterations in flight, and the sum of the shards in rank order is that process's image bit for bit. */
+ * of n computes exactly the iterations g+1, g+1+n, ... of a single-GPU render: its radiance buffer is the running sum of exactly
+ * those iterations, bit for bit, and the sum of the shards is the single-GPU image up to float association (the same
+ * per-iteration radiances, added shard by shard instead of in iteration order). */
 int ptk_set_iteration_sharding(int n_shards, int shard);
 /* Bounces currently enqueued at full width (the remaining ones run in the single-workgroup tail kernel); diagnostic. */
 int ptk_get_full_width_bounces(int* out);

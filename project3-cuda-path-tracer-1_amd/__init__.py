@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
     "ptk_set_pipeline", "ptk_stream_sync", "ptk_timer_start", "ptk_timer_stop",
     "ptk_profile_begin", "ptk_profile_end", "ptk_enable_traversal_stats", "ptk_get_traversal_stats",
-    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_tiles_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_light_fix",
+    "ptk_partition_count", "ptk_partition_pixel", "ptk_set_iterations_in_flight", "ptk_set_ordered_accumulation", "ptk_set_tiles_in_flight", "ptk_set_graph_replay", "ptk_set_samples_per_launch", "ptk_set_light_fix",
     "ptk_set_iteration_sharding", "ptk_get_full_width_bounces", "ptk_get_open_scene_hint",
 ]
 # include/ptk_test_hooks.h: exported by libptk_hooks.so (PTK_FLAVOUR=hooks) only, never by the product library
@@ -142,6 +142,7 @@ def _load() -> C.CDLL:
     lib.ptk_set_pipeline.argtypes = [ci]
     lib.ptk_set_iterations_in_flight.argtypes = [ci]
     lib.ptk_set_tiles_in_flight.argtypes = [ci]
+    lib.ptk_set_ordered_accumulation.argtypes = [ci]
     lib.ptk_set_graph_replay.argtypes = [ci]
     lib.ptk_set_samples_per_launch.argtypes = [ci]
     lib.ptk_set_light_fix.argtypes = [ci]
@@ -312,9 +313,10 @@ class Renderer:
     """File-static render context of the library (one at a time, like the reference)."""
 
     def __init__(self, scene: Scene, mode: int = MODE_MIS, partition=(1, 0, 1), pipeline: int = 0, in_flight: int = 1,
-                 graph: bool = False, spp: int = 1, shard=(1, 0), tiles: int = 1):
+                 graph: bool = False, spp: int = 1, shard=(1, 0), tiles: int = 1, ordered: int = -1):
         """shard = (n, g): iterate(step) renders iteration (step-1)*n + g + 1 of the whole frame (ptk_set_iteration_sharding);
-        tiles = K: K bands of rows in flight, bit-identical to the default (ptk_set_tiles_in_flight)"""
+        tiles = K: K bands of rows in flight, bit-identical to the default (ptk_set_tiles_in_flight);
+        ordered: accumulation with several planes (ptk_set_ordered_accumulation; -1 = ordered unless `mode` is MIS)"""
         self.scene = scene
         lib.ptk_pathtrace_free()
         _chk(lib.ptk_set_iteration_sharding(*shard), "ptk_set_iteration_sharding")
@@ -322,6 +324,7 @@ class Renderer:
         _chk(lib.ptk_set_graph_replay(1 if graph else 0), "ptk_set_graph_replay")
         _chk(lib.ptk_set_iterations_in_flight(in_flight), "ptk_set_iterations_in_flight")
         _chk(lib.ptk_set_tiles_in_flight(tiles), "ptk_set_tiles_in_flight")
+        _chk(lib.ptk_set_ordered_accumulation(ordered), "ptk_set_ordered_accumulation")
         _chk(lib.ptk_set_pipeline(pipeline), "ptk_set_pipeline")
         _chk(lib.ptk_set_tile_partition(*partition), "ptk_set_tile_partition")
         _chk(lib.ptk_set_sample_mode(mode), "ptk_set_sample_mode")
@@ -400,6 +403,7 @@ class Renderer:
         lib.ptk_set_tile_partition(1, 0, 1)
         lib.ptk_set_iterations_in_flight(1)
         lib.ptk_set_tiles_in_flight(1)
+        lib.ptk_set_ordered_accumulation(-1)
         lib.ptk_set_graph_replay(0)
         lib.ptk_set_samples_per_launch(1)
         lib.ptk_set_iteration_sharding(1, 0)

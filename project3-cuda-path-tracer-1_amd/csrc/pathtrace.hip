@@ -37,7 +37,7 @@ struct Lane {
     PtkHits hits = {nullptr, nullptr, nullptr}, hitsB = {nullptr, nullptr, nullptr};     // hitsB, hrA/hrB: fused pipeline (hit records ping-pong with the paths)
     int* hrA = nullptr; int* hrB = nullptr;
     Workspace ws;
-    float* plane = nullptr;             // float[3*P] radiance sum of this lane's iterations (points into RenderContext::planes)
+    float* plane = nullptr;             // float[spp][3*P]: the radiance of the launch in flight on this lane, merged into the image when it is done (merge_lane); the image itself with one lane, one sample per launch or tiles in flight
     int last_iter = 0;
     // hipGraph replay of one iteration (all launches of render_iteration): the iteration number lives on the device
     int* iter_dev = nullptr;
@@ -51,7 +51,8 @@ struct Lane {
     int graph_full = -1;                // full-width bounces the captured graph contains
     int graph_late = -1;                // the camera launch's store placement the captured graph contains (g.gen_late)
     int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
-    bool wait_resolved = false;         // the next enqueue must wait for lane 0's plane sum (resolve_image) to have read this lane's plane
+    hipEvent_t merged = nullptr;        // ordered accumulation: recorded after this lane's merge_lane
+    bool wait_resolved = false;         // the next enqueue must wait for lane 0's asynchronous reader of the planes / the image (plane sum, tone map of the previous pbo)
     int fresh_hint = 0;                 // iterations enqueued on this lane since the hint was reset (read-backs every iteration at first)
     // what this lane renders: the whole frame / this rank's tiles (iterations in flight), or ONE band of rows (tiles in flight)
     int n_parts = 1, part = 0, tile_rows = 1, n_pix = 0, capacity = 0;
@@ -68,9 +69,12 @@ struct RenderContext {
     GuiDataContainer* gui = nullptr;
     std::vector<Lane> lanes;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t resolved = nullptr;      // recorded on lane 0 after k_sum_planes
-    float* planes = nullptr;            // float[L][3*P]
-    float* image = nullptr;             // float[3*P]: plane sum when L > 1 (== planes when L == 1)
+    hipEvent_t resolved = nullptr;      // recorded on lane 0 after an asynchronous reader of the image (ptk_pathtrace's tone map)
+    float* planes = nullptr;            // float[L][spp][3*P]
+    float* image = nullptr;             // float[3*P]: the running sum, in iteration order (== planes when there is one plane)
+    int want_ordered = -1;              // ptk_set_ordered_accumulation: -1 auto (ordered unless the sample mode at ptk_pathtrace_init is MIS), 0, 1
+    bool ordered = false;               // several planes AND ordered accumulation (merge_lane); false: the planes accumulate, resolve_image sums them
+    hipEvent_t last_merged = nullptr;   // ordered accumulation: the event of the latest merge (some lane's `merged`), nullptr before the first
     unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
     int n_parts = 1, part = 0, tile_rows = 1;
@@ -124,6 +128,7 @@ int context_free() {
         if (l.graph) (void)hipGraphDestroy(l.graph);
         if (l.done) (void)hipEventDestroy(l.done);
         if (l.counts_ev) (void)hipEventDestroy(l.counts_ev);
+        if (l.merged) (void)hipEventDestroy(l.merged);
         if (l.h_counts) (void)hipHostFree(l.h_counts);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
@@ -135,6 +140,7 @@ int context_free() {
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
     if (g.resolved) { (void)hipEventDestroy(g.resolved); g.resolved = nullptr; }
+    g.last_merged = nullptr; g.ordered = false;
     g.live = false; g.tiles = false; g.scene = nullptr; g.P = g.capacity = 0;
     return 0;
 }
@@ -183,6 +189,7 @@ int lane_init(Lane& l, int idx) {
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreateWithFlags(&l.merged, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipHostMalloc((void**)&l.h_counts, sizeof(int) * 2 * ((size_t)g.traceDepth + 2), hipHostMallocDefault)) != hipSuccess) return (int)e;      // counts, then hcounts
     const Camera& cam = g.scene->state.camera;
     if (g.tiles) {
@@ -251,6 +258,8 @@ int lane_init(Lane& l, int idx) {
     return 0;
 }
 
+int current_mode();
+
 int context_init(Scene* scene) {
     if (!scene || !scene->ok) return PTK_E_NOSCENE;
     if (!scene->tempDevScene.uploaded) { scene->setDevData(); if (scene->devError) return scene->devError; }
@@ -285,7 +294,12 @@ int context_init(Scene* scene) {
     const size_t n_planes = g.tiles ? 1 : (size_t)g.n_lanes * g.spp;
     if ((rc = dalloc(&g.planes, plane * n_planes))) return rc;
     if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * n_planes)) != hipSuccess) return (int)e;
-    if (n_planes > 1) { if ((rc = dalloc(&g.image, plane))) return rc; } else g.image = g.planes;
+    if (n_planes > 1) {
+        if ((rc = dalloc(&g.image, plane))) return rc;
+        if ((e = hipMemset(g.image, 0, sizeof(float) * plane)) != hipSuccess) return (int)e;
+    } else g.image = g.planes;
+    g.ordered = n_planes > 1 && (g.want_ordered >= 0 ? g.want_ordered != 0 : current_mode() != PTK_MODE_MIS);
+    g.last_merged = nullptr;
     if ((rc = dalloc(&g.ray_total, 1))) return rc;
     if ((e = hipMemset(g.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return (int)e;
     if (g.pipeline == 5 && scene->tempDevScene.n_copies != 6 && (rc = scene->tempDevScene.upload_threaded(*scene, 6))) return rc;
@@ -344,6 +358,8 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     ws.iter_stride = (g.tiles ? 1 : g.n_lanes) * g.n_shards;       // (tiles in flight: every lane renders every iteration)
     ws.dbg_shift0 = g_debug_slot_shift; ws.dbg_shift_deep = g_debug_slot_shift_deep;
     ws.gen_late = L.gen_late;
+    // ordered accumulation in BSDF / DIRECT: the lane's planes are zero when the launch starts and a pixel receives at most one add — a plain store
+    if (g.ordered && mode != PTK_MODE_MIS) ws.plane_stride |= PTK_FILM_STORE;
     if (g.tiles) {
         const int li = (int)(&L - &g.lanes[0]);
         ws.cum_prev = li > 0 ? g.lanes[li - 1].cum : nullptr; ws.cum_out = L.cum; ws.cum_stride = g.traceDepth + 2; ws.ring_div = g.n_shards;
@@ -473,9 +489,30 @@ int replay_iteration(Lane& L, int iter, int mode) {
 
 static void reset_hints() { for (Lane& l : g.lanes) { l.full_bounces = g.traceDepth; l.gen_late = 0; l.counts_pending = false; l.fresh_hint = 0; } }
 
+// ORDERED ACCUMULATION (round 4).  With several planes (iterations in flight, samples per launch) a launch adds its radiance into the lane's own
+// planes, zero when it starts, and this merge — on the lane's stream, behind the launch — folds them into the image in ITERATION order: it waits
+// for the merge of the previous call (another lane's stream; one event edge, no host wait).  image = ((image + it_1) + it_2) + ...: the
+// reference's running sum (pathtrace.cu:600).  BSDF / DIRECT add at most once per pixel and iteration, so the image is bit-identical to one
+// iteration at a time; MIS adds bounce by bounce, the plane holds the iteration's own sum and only the float association differs
+// (ptk_kernels.hip: k_merge_planes).  The lane's next launch follows the merge on the same stream and finds its planes zero again.
+// (Measured and dropped: the merges on a stream of their own, so that no lane waits for another — a fourth stream beside three lanes shares a
+// hardware queue with one of them, cornell 21.9 -> 15.2 Grays/s.)  Cost: one launch per iteration that reads the whole plane — cornell BSDF -1.4 .. -3.3 %,
+// DIRECT -5 %, mis_test 1024^2 BSDF (a 42-us iteration) -12 % (profiles/r4_ab_ordered_accumulation.txt) — which is why MIS, where ordering cannot make the image bit-identical anyway, keeps accumulating
+// planes (ptk_set_ordered_accumulation: auto).
+static int merge_lane(Lane& L) {
+    if (!g.ordered) return 0;                            // one plane (the launches add into the image itself), or planes that accumulate (resolve_image)
+    hipError_t e;
+    if (g.last_merged && g.last_merged != L.merged && (e = hipStreamWaitEvent(L.stream, g.last_merged, 0)) != hipSuccess) return (int)e;
+    const int rc = launch_merge_planes(g.image, L.plane, g.spp, 3 * (size_t)g.P, L.stream);
+    if (rc) return rc;
+    if ((e = hipEventRecord(L.merged, L.stream)) != hipSuccess) return (int)e;
+    g.last_merged = L.merged;
+    return 0;
+}
+
 // one iteration of one lane: replayed from its hipGraph or enqueued launch by launch
 static int lane_iteration(Lane& L, int iter, int mode) {
-    if (L.wait_resolved) {                   // lane 0 may still be summing / tone-mapping this lane's radiance for the previous pbo
+    if (L.wait_resolved) {                   // lane 0 may still be summing this lane's planes / tone-mapping the image its merge adds to, for the previous pbo
         const hipError_t e = hipStreamWaitEvent(L.stream, g.resolved, 0);
         if (e != hipSuccess) return (int)e;
         L.wait_resolved = false;
@@ -486,7 +523,8 @@ static int lane_iteration(Lane& L, int iter, int mode) {
     int rc;
     if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
     else { L.expected_iter = -1; rc = enqueue_iteration(L, iter, mode, false); }
-    return rc ? rc : request_counts(L);
+    if (rc || (rc = request_counts(L))) return rc;
+    return merge_lane(L);
 }
 
 int render_iteration(unsigned char* pbo, int step) {
@@ -538,13 +576,18 @@ int join_on_lane0() {
     return 0;
 }
 
-// image = ((plane0 + plane1) + plane2) + ...   on lane 0's stream, after joining the other lanes
+// the image as of the last call, on lane 0's stream after joining the other lanes (event edges, no host wait): the running sum itself (one
+// plane, tiles in flight, ordered accumulation), or ((plane0 + plane1) + plane2) + ... of planes that accumulate
 int resolve_image() {
     int rc = join_on_lane0();
     if (rc) return rc;
-    if (!g.tiles && g.n_lanes * g.spp > 1) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
-    if (rc || g.n_lanes == 1) return rc;
-    // the other lanes' next iterations write the planes this sum reads: they wait for it (event edge, no host wait)
+    if (g.image != g.planes && !g.ordered) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
+    return rc;
+}
+// asynchronous readers on lane 0 were enqueued (the plane sum above, the tone map of ptk_pathtrace): the other lanes' next launches write the
+// planes / merge into the image they read — they wait for them (event edge, no host wait)
+int image_reader_enqueued() {
+    if (g.n_lanes == 1 || g.image == g.planes) return 0;
     const hipError_t e = hipEventRecord(g.resolved, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
     for (size_t i = 1; i < g.lanes.size(); ++i) g.lanes[i].wait_resolved = true;
@@ -572,7 +615,8 @@ int ptk_pathtrace(unsigned char* pbo, int frame, int iter) {
     if ((rc = resolve_image())) return rc;
     const Camera& cam = g.scene->state.camera;
     // samples accumulated so far by THIS process (with iteration sharding a call is one sample, whatever its iteration number)
-    return ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter * g.spp, pbo, g.lanes[0].stream);
+    if ((rc = ptk_tonemap(g.image, cam.resolution.x, cam.resolution.y, iter * g.spp, pbo, g.lanes[0].stream))) return rc;
+    return image_reader_enqueued();
 }
 
 int ptk_set_sample_mode(int mode) { if (mode < 0 || mode > 2) return PTK_E_BADARG; g_mode_override = mode; return 0; }
@@ -585,6 +629,15 @@ int ptk_get_sample_mode(void) { return current_mode(); }
 int ptk_set_tiles_in_flight(int tiles) {
     if (tiles < 1 || tiles > kMaxLanes || g.live) return PTK_E_BADARG;
     g.want_tiles = tiles;
+    return 0;
+}
+/* Accumulation with several radiance planes (iterations in flight, samples per launch; set before ptk_pathtrace_init): 1 = ordered — every
+ * launch's planes are folded into the image in call order (merge_lane: BSDF / DIRECT bit-identical to one iteration at a time); 0 = the planes
+ * accumulate and are summed when the image is read, ((p0 + p1) + p2) + ...; -1 (default) = ordered unless the sample mode at
+ * ptk_pathtrace_init is MIS, whose bounce-by-bounce adds no order can make bit-identical (so it skips the merges' cost). */
+int ptk_set_ordered_accumulation(int on) {
+    if (on < -1 || on > 1 || g.live) return PTK_E_BADARG;
+    g.want_ordered = on;
     return 0;
 }
 int ptk_set_iterations_in_flight(int lanes) {
@@ -693,8 +746,8 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j) {
 }
 /* Iteration sharding (SURVEY 8e validation mode; set before ptk_pathtrace_init): ptk_pathtrace(.., step) renders iteration
  * (step-1)*n_shards + shard + 1 of the WHOLE frame with the reference's own RNG keys (camera key (x, y, iter), pathtrace.cu:148;
- * shading key (iter, compacted slot, depth), :458,532).  Shard g of n then holds exactly the radiance plane g of a single
- * process running n iterations in flight; the sum of the shards in rank order is that process's image, bit for bit. */
+ * shading key (iter, compacted slot, depth), :458,532).  Shard g of n then holds the running sum of exactly the iterations g+1, g+1+n,
+ * ...; the sum of the shards is the single-process image up to float association. */
 int ptk_set_iteration_sharding(int n_shards, int shard) {
     if (n_shards < 1 || shard < 0 || shard >= n_shards || g.live) return PTK_E_BADARG;
     g.n_shards = n_shards; g.shard = shard;
@@ -727,7 +780,8 @@ int ptk_debug_slot_shift(int k0, int k1) { g_debug_slot_shift = k0; g_debug_slot
 int ptk_debug_clear_image(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();
-    const int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp)));
+    int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp)));
+    if (!rc && g.image != g.planes) rc = rc_of(hipMemset(g.image, 0, sizeof(float) * 3 * (size_t)g.P));
     return rc ? rc : rc_of(hipDeviceSynchronize());      // null-stream clear vs the lanes' non-blocking streams
 }
 #endif
@@ -819,14 +873,15 @@ int ptk_timer_stop(float* ms) {
 void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
 // Knobs of the C++ API, read at pathtraceInit (the four reference signatures have no room for them): PTK_IN_FLIGHT=<L> iterations in flight,
-// PTK_TILES=<K> tiles in flight (bit-identical image; wants PTK_GRAPH=1), PTK_GRAPH=1 hipGraph replay (all as ptk_set_*; defaults 1 / 1 / 0 = the
-// reference's accumulation order), PTK_EAGER_IMAGE=1 = refresh
+// PTK_TILES=<K> tiles in flight (bit-identical image; wants PTK_GRAPH=1), PTK_GRAPH=1 hipGraph replay, PTK_ORDERED=-1|0|1 accumulation with several
+// planes (all as ptk_set_*; defaults 1 / 1 / 0 / -1 = the reference's accumulation order), PTK_EAGER_IMAGE=1 = refresh
 // scene->state.image after EVERY call like pathtrace.cu:809-810 (a 7.7 MB D2H and a host wait per 0.3 ms iteration at 800 x 800).
 void pathtraceInit(Scene* scene) {
     if (!g.live) {
         if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.n_lanes = l; }
         if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;
         if (const char* e = getenv("PTK_TILES")) { const int t = atoi(e); if (t >= 1 && t <= kMaxLanes) g.want_tiles = t; }
+        if (const char* e = getenv("PTK_ORDERED")) { const int o = atoi(e); if (o >= -1 && o <= 1) g.want_ordered = o; }
     }
     PTK_CHECK("pathtraceInit", context_init(scene));
     g.eager_image = getenv("PTK_EAGER_IMAGE") && atoi(getenv("PTK_EAGER_IMAGE")) != 0;

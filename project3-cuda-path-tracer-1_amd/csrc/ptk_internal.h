@@ -15,6 +15,7 @@ namespace ptk {
 // BVH walk of the work-list rays (both give bit-identical hits): the reference's threaded walk, one ray per lane (fewest
 // instructions, longest dependent chain); four lanes per ray over the 8-wide collapsed tree (default).
 enum { PTK_WALK_AUTO = 0, PTK_WALK_THREADED = 1, PTK_WALK_WIDE = 2 };
+#define PTK_FILM_STORE 0x80000000u   // bit 31 of Workspace::plane_stride: radiance adds are plain stores (ptk_kernels.hip: pixel_ptr / film_add)
 enum { PTK_CUM_RING = 4 };       // iterations a band may run ahead of the band below it (tiles in flight), power of two
 
 void set_light_fix(bool on);            // opt-in fixed cube lights (ptk_set_light_fix)
@@ -53,7 +54,7 @@ struct Workspace {               // per-render-context scratch, device memory
     int* list = nullptr;         // the work list [capacity]
     int* iter_dev = nullptr;     // device-resident iteration number (hipGraph replay); null = use the launch argument
     int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
-    unsigned plane_stride = 0;   // floats per radiance plane (3*P)
+    unsigned plane_stride = 0;   // floats per radiance plane (3*P); bit 31 = PTK_FILM_STORE (ptk_kernels.hip: pixel_ptr)
     int spp = 1;                 // samples (iterations) per launch
     int slot_bias = 0;           // added to the compacted slot in the shading RNG key: part * W * H * spp under the tile partition, so
                                  // that two ranks never share a random stream (0 on one GPU = the reference's key)
@@ -90,7 +91,8 @@ struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; };
 int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool));
-int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);
+int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);      // out = ((p0 + p1) + p2) + ...
+int launch_merge_planes(float* image, float* planes, int n_planes, size_t plane_len, hipStream_t st);      // image += planes in order; planes = 0
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);
 
 } // namespace ptk

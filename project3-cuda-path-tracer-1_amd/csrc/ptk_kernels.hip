@@ -127,10 +127,19 @@ __device__ __forceinline__ int prefix_block(int nw, const int* __restrict__ agg,
 
 // pixelIndex -> its three floats in the radiance planes.  With samples per launch (spp > 1) bits 24..30 of pixelIndex carry the sample's
 // plane; a launch with spp == 1 passes plane_stride = 0 and all 31 bits are the pixel (frames of 2^24 pixels and more).  Wave-uniform selects.
+// Bit 31 of plane_stride (PTK_FILM_STORE; 3 P < 2^31, pathtrace.hip: context_init): the launch adds into a plane that is zero when the iteration starts
+// and receives at most ONE add per pixel (ordered accumulation in BSDF / DIRECT mode) — the add is a plain store, no dependent load.
 __device__ __forceinline__ float* pixel_ptr(float* img, unsigned plane_stride, int pix) {
-    const unsigned mask = plane_stride ? 0xFFFFFFu : 0x7FFFFFFFu;
-    const unsigned plane = plane_stride ? ((unsigned)pix >> 24) : 0u;
-    return img + (size_t)plane * plane_stride + 3 * (size_t)((unsigned)pix & mask);
+    const unsigned stride = plane_stride & ~PTK_FILM_STORE;
+    const unsigned mask = stride ? 0xFFFFFFu : 0x7FFFFFFFu;
+    const unsigned plane = stride ? ((unsigned)pix >> 24) : 0u;
+    return img + (size_t)plane * stride + 3 * (size_t)((unsigned)pix & mask);
+}
+__device__ __forceinline__ void film_add(float* img, unsigned plane_stride, int pix, f3 c) {
+    // one live path per (sample plane, pixel): plain read-modify-write, no atomics.  plane = pix >> 24 (0 unless spp > 1)
+    float* p = pixel_ptr(img, plane_stride, pix);
+    if (plane_stride & PTK_FILM_STORE) { p[0] = c.x; p[1] = c.y; p[2] = c.z; }      // wave-uniform
+    else { p[0] += c.x; p[1] += c.y; p[2] += c.z; }
 }
 __device__ __forceinline__ float4 ld4(const float* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
 __device__ __forceinline__ void st4(float* p, int i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
@@ -882,8 +891,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg,
     const float4 d4 = ld4(paths.d_bnc, g), c4 = ld4(paths.col_pdf, g);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)g + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
-    float* p = pixel_ptr(img, plane_stride, pix);
-    p[0] += c.x; p[1] += c.y; p[2] += c.z;
+    film_add(img, plane_stride, pix, c);
 }
 
 // environment map on a miss (pathtrace.cu:303-311): img[pixel] += processNAN(color * env(sphere2Plane(direction)))
@@ -897,8 +905,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, 
     const float4 d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)i + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
-    float* p = pixel_ptr(img, plane_stride, pix);
-    p[0] += c.x; p[1] += c.y; p[2] += c.z;
+    film_add(img, plane_stride, pix, c);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -909,9 +916,7 @@ struct PathRegs { f3 o, d, col; int pix, bounces; float prevPdf; };
 
 struct Film { float* img; unsigned plane_stride; };       // radiance planes: float[plane][3*P]
 __device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
-    // one live path per (sample plane, pixel): plain read-modify-write, no atomics.  plane = pix >> 24 (0 unless spp > 1)
-    float* p = pixel_ptr(film.img, film.plane_stride, pix);
-    p[0] += c.x; p[1] += c.y; p[2] += c.z;
+    film_add(film.img, film.plane_stride, pix, c);
 }
 
 // Material records staged in LDS by the shading kernel (first PTK_LDS_MATS materials; the rest, if any, come from global memory):
@@ -1997,13 +2002,47 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_tonemap(const float* __restrict__
     pbo[i] = make_uchar4((unsigned char)c[0], (unsigned char)c[1], (unsigned char)c[2], 0);
 }
 
-// image = ((plane0 + plane1) + plane2) + ...  (fixed order -> deterministic)
+// unordered accumulation (MIS with several planes, pathtrace.hip: resolve_image): image = ((plane0 + plane1) + plane2) + ...  (fixed order -> deterministic)
 __global__ void __launch_bounds__(PTK_BLOCK) k_sum_planes(const float* __restrict__ planes, int n_planes, size_t plane_len, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= plane_len) return;
     float s = planes[i];
     for (int p = 1; p < n_planes; ++p) s += planes[(size_t)p * plane_len + i];
     out[i] = s;
+}
+
+// ORDERED ACCUMULATION (round 4; pathtrace.hip: merge_lane).  With several iterations in flight (or several samples per launch) an iteration
+// adds its radiance into a plane of its own, zero when it starts; this kernel then folds the launch's planes into the image IN ITERATION ORDER and
+// leaves them zero for the lane's next launch: image = ((image + it_1) + it_2) + ... — the reference's running sum (pathtrace.cu:600).  In BSDF and
+// DIRECT mode a pixel receives at most one add per iteration, its plane value IS that add and image + 0 == image: the image is bit-identical to
+// one iteration at a time.  (MIS adds next-event terms bounce by bounce; there the plane holds the iteration's own sum and the result differs from
+// the reference's in float association only.)  Elements whose planes are all zero are neither read from nor written to the image.
+template <typename V>
+__global__ void __launch_bounds__(PTK_BLOCK) k_merge_planes(float* __restrict__ image, float* __restrict__ planes, int n_planes, size_t plane_len) {
+    constexpr int N = sizeof(V) / sizeof(float);
+    const size_t i = ((size_t)blockIdx.x * PTK_BLOCK + threadIdx.x) * N;
+    if (i >= plane_len) return;
+    V v;
+    bool have = false;
+    for (int p = 0; p < n_planes; ++p) {
+        V* src = reinterpret_cast<V*>(planes + (size_t)p * plane_len + i);
+        const V a = *src;
+        const float* af = reinterpret_cast<const float*>(&a);
+        bool nz = false;
+#pragma unroll
+        for (int k = 0; k < N; ++k) nz |= af[k] != 0.0f;
+        if (!nz) continue;
+        if (!have) { v = *reinterpret_cast<const V*>(image + i); have = true; }
+        float* vf = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) vf[k] += af[k];
+        V z;
+        float* zf = reinterpret_cast<float*>(&z);
+#pragma unroll
+        for (int k = 0; k < N; ++k) zf[k] = 0.0f;
+        *src = z;
+    }
+    if (have) *reinterpret_cast<V*>(image + i) = v;
 }
 
 #ifdef PTK_TEST_HOOKS
@@ -2354,6 +2393,16 @@ bool light_fix_enabled() { return g_light_fix; }
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st) {
     const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
     k_sum_planes<<<g, PTK_BLOCK, 0, st>>>(planes, n_planes, plane_len, out);
+    return launch_rc();
+}
+int launch_merge_planes(float* image, float* planes, int n_planes, size_t plane_len, hipStream_t st) {
+    if (plane_len % 4 == 0) {                      // every plane then starts on a 16-byte boundary
+        const int g = (int)((plane_len / 4 + PTK_BLOCK - 1) / PTK_BLOCK);
+        k_merge_planes<float4><<<g, PTK_BLOCK, 0, st>>>(image, planes, n_planes, plane_len);
+    } else {
+        const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
+        k_merge_planes<float><<<g, PTK_BLOCK, 0, st>>>(image, planes, n_planes, plane_len);
+    }
     return launch_rc();
 }
 

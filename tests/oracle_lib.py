@@ -168,6 +168,58 @@ class Scene:
             pass
 
 
+class Accumulator:
+    """The product's accumulation, restated for the checks (csrc/pathtrace.hip: merge_lane / resolve_image; include/ptk.h:
+    ptk_set_ordered_accumulation).  ONE radiance plane (one iteration at a time, one sample per launch; tiles in flight): every add goes into the
+    image itself, as in the reference (pathtrace.cu:556,572,600).  SEVERAL planes (L iterations in flight and / or S samples per launch):
+      ordered  — a launch adds into planes of its own, zero when it starts, which are folded into the image in call order when it is done:
+                 image = ((image + it_1) + it_2) + ...; BSDF / DIRECT add at most once per pixel and iteration, so this IS the plain running sum;
+      otherwise — lane l's planes accumulate its calls l+1, l+1+L, ... and the image is ((plane_0 + plane_1) + plane_2) + ... over lanes x samples.
+    ordered=None follows the product's default: ordered unless the sample mode at init is MIS."""
+
+    def __init__(self, P, lanes=1, spp=1, mode=0, ordered=None):
+        self.lanes, self.spp = lanes, spp
+        self.single = lanes * spp <= 1
+        self.ordered = (mode != MODE_MIS) if ordered is None else bool(ordered)
+        self.image = np.zeros((P, 3), np.float32)
+        self.planes = None if (self.single or self.ordered) else np.zeros((lanes, spp, P, 3), np.float32)
+
+    def iteration(self, scene, mode, it, partition=(1, 0, 1), step=None):
+        """one call of ptk_pathtrace(.., step) with one sample per launch; it = the iteration it renders (== step unless iterations are sharded)"""
+        assert self.spp == 1
+        step = it if step is None else step
+        if self.single:
+            return scene.pathtrace(mode, it, self.image, partition=partition)
+        if self.ordered:
+            tmp = np.zeros_like(self.image)
+            r = scene.pathtrace(mode, it, tmp, partition=partition)
+            self.image += tmp
+            return r
+        return scene.pathtrace(mode, it, self.planes[(step - 1) % self.lanes][0], partition=partition)
+
+    def batch(self, scene, mode, step, partition=(1, 0, 1)):
+        """one call of ptk_pathtrace(.., step) with spp samples per launch"""
+        if self.single:
+            return scene.pathtrace_batch(mode, step, 1, self.image.reshape(1, -1, 3), partition=partition)
+        if self.ordered:
+            tmp = np.zeros((self.spp,) + self.image.shape, np.float32)
+            r = scene.pathtrace_batch(mode, step, self.spp, tmp, partition=partition)
+            for s in range(self.spp):
+                self.image += tmp[s]
+            return r
+        return scene.pathtrace_batch(mode, step, self.spp, self.planes[(step - 1) % self.lanes], partition=partition)
+
+    @property
+    def img(self):
+        if self.planes is None:
+            return self.image
+        flat = self.planes.reshape(self.lanes * self.spp, -1, 3)
+        out = flat[0].copy()
+        for p in flat[1:]:
+            out = out + p
+        return out
+
+
 def compact(valid, paths, isects=None):
     keep = valid.astype(bool)
     return paths[keep].copy(), (isects[keep].copy() if isects is not None else None)

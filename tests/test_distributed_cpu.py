@@ -154,18 +154,21 @@ def _iter_shard_worker(rank, world, port, steps, out_dir):
 
 def test_two_rank_iteration_sharding_is_the_single_process_render(tmp_path, orc, scenes_dir):
     """SURVEY 8e validation mode, CPU tier: rank g of 2 renders iterations g+1, g+3, ... of the whole frame with the reference's own
-    keys; the SUM-reduced buffer equals (plane0 + plane1) of ONE process that renders iterations 1..2K with plane l = iterations
-    l+1, l+3, ... (what the product does with two iterations in flight), bit for bit, and the ray counts add up."""
+    keys; the SUM-reduced buffer is the sum of the two ranks' running sums, bit for bit, the ray counts add up, and it is ONE process's
+    render of iterations 1..2K — the same per-iteration radiances added as (1 + 3 + 5) + (2 + 4 + 6) instead of 1, 2, 3, ...: equal up to
+    float association (1e-5 relative, written here)."""
     world, steps = 2, 3
     mp.spawn(_iter_shard_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
     img = np.load(tmp_path / "img.npy"); rays = int(np.load(tmp_path / "rays.npy")[0])
     orc.set_trig_mode(orc.TRIG_PTK)
     s = orc.Scene(os.path.join(scenes_dir, "cornell.txt"), res=(48, 40), depth=3)
-    planes = np.zeros((world, s.P, 3), np.float32); ref = 0
+    shards = np.zeros((world, s.P, 3), np.float32); single = np.zeros((s.P, 3), np.float32); ref = 0
     for it in range(1, world * steps + 1):
-        r, _ = s.pathtrace(0, it, planes[(it - 1) % world]); ref += r
+        r, _ = s.pathtrace(0, it, shards[(it - 1) % world]); ref += r
+        s.pathtrace(0, it, single)
     assert rays == ref
-    assert np.array_equal(img, planes[0] + planes[1])
+    assert np.array_equal(img, shards[0] + shards[1])
+    assert np.allclose(img, single, rtol=1e-5, atol=1e-6)
     assert img.sum() > 0
     s.close()
 

@@ -54,14 +54,10 @@ def test_two_ranks_tiles_times_samples(tmp_path, orc):
     o = orc.Scene(os.path.join(ROOT, "scenes", SCENE), res=RES, depth=DEPTH)
     total = np.zeros((o.P, 3), np.float32); ref_rays = 0
     for rank in range(world):
-        planes = np.zeros((LANES, SPP, o.P, 3), np.float32)
+        acc = orc.Accumulator(o.P, LANES, SPP, MODE)
         for step in range(1, STEPS + 1):
-            rr, _ = o.pathtrace_batch(MODE, step, SPP, planes[(step - 1) % LANES], partition=(world, rank, ROWS)); ref_rays += rr
-        flat = planes.reshape(LANES * SPP, o.P, 3)
-        part = flat[0].copy()
-        for p in flat[1:]:
-            part = part + p
-        total = total + part              # disjoint supports: exact for any reduce order
+            rr, _ = acc.batch(o, MODE, step, partition=(world, rank, ROWS)); ref_rays += rr
+        total = total + acc.img           # disjoint supports: exact for any reduce order
     assert rays == ref_rays
     bad = np.flatnonzero((img != total).any(axis=1))
     assert bad.size == 0, f"{bad.size} pixels differ, first {bad[:8]}: {img[bad[:4]]} vs {total[bad[:4]]}"
@@ -99,10 +95,10 @@ def _iter_worker(rank, world, port, out_dir, lanes):
 @pytest.mark.parametrize("lanes", [1, 2])
 def test_two_ranks_iteration_sharded_equals_single_process(tmp_path, ptk, orc, lanes):
     """Rank g of 2 renders iterations g+1, g+3, ... of the whole frame (ptk_set_iteration_sharding) with the reference's own RNG keys
-    (pathtrace.cu:148,458,532).  With one iteration at a time per rank, shard g IS radiance plane g of a single process with two
-    iterations in flight, so the SUM-reduced image equals that process's image bit for bit (two addends: any reduce order), and every
-    shard equals the oracle's sum of exactly its iterations.  With two lanes per rank the shard is (lane0 + lane1) of its own
-    iterations — compared with the oracle's planes summed the same way."""
+    (pathtrace.cu:148,458,532).  Every shard equals the oracle's running sum of exactly its iterations, bit for bit (one or two of them in
+    flight per rank: ordered accumulation), and the SUM-reduced image is shard0 + shard1 (two addends: any reduce order).  The single-process
+    render traces the same paths (equal ray totals) and adds the same per-iteration radiances in the order 1, 2, 3, ... instead of
+    (1 + 3 + 5 ...) + (2 + 4 + 6 ...): equal up to float association (1e-5 relative, written here)."""
     world = 2
     mp.spawn(_iter_worker, args=(world, _free_port(), str(tmp_path), lanes), nprocs=world, join=True)
     img = np.load(tmp_path / "img.npy"); rays = int(np.load(tmp_path / "rays.npy")[0])
@@ -111,18 +107,16 @@ def test_two_ranks_iteration_sharded_equals_single_process(tmp_path, ptk, orc, l
     ref_rays = 0
     shards = []
     for rank in range(world):
-        planes = np.zeros((lanes, o.P, 3), np.float32)
+        acc = orc.Accumulator(o.P, lanes, 1, MODE)
         for step in range(1, IT_STEPS + 1):
-            rr, _ = o.pathtrace(MODE, (step - 1) * world + rank + 1, planes[(step - 1) % lanes]); ref_rays += rr
-        sh = planes[0].copy()
-        for p in planes[1:]:
-            sh = sh + p
+            rr, _ = acc.iteration(o, MODE, (step - 1) * world + rank + 1, step=step); ref_rays += rr
+        sh = acc.img
         shards.append(sh)
         assert np.array_equal(np.load(tmp_path / f"shard{rank}.npy"), sh)
     assert rays == ref_rays
     assert np.array_equal(img, shards[0] + shards[1])
     if lanes == 1:
-        # the single-process run with iterations_in_flight = 2: plane l sums iterations l+1, l+3, ...; image = plane0 + plane1
+        # the single-process run with iterations_in_flight = 2 (ordered accumulation: the reference's running sum)
         scene = ptk.Scene(os.path.join(ROOT, "scenes", SCENE), res=RES, depth=DEPTH)
         r = ptk.Renderer(scene, MODE, in_flight=2, graph=True)
         for it in range(1, world * IT_STEPS + 1):
@@ -130,7 +124,7 @@ def test_two_ranks_iteration_sharded_equals_single_process(tmp_path, ptk, orc, l
         single = r.image(); single_rays = r.ray_total()
         r.close()
         assert single_rays == rays
-        assert np.array_equal(img, single)
+        assert np.allclose(img, single, rtol=1e-5, atol=1e-6)
 
 
 def test_bench_self_launches_two_ranks(tmp_path):

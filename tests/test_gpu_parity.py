@@ -146,15 +146,15 @@ def test_textured_scene(ptk, orc, torch_cuda, tmp_path, mode, env):
     lanes = 2
     for pipeline in (0, 10):             # the staged kernels (default with triangles) and the fused launches + k_env_miss2
         r = ptk.Renderer(s, m, in_flight=lanes, pipeline=pipeline)
-        planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+        acc = orc.Accumulator(o.P, lanes, 1, m)
         for it in (1, 2, 3, 4):
             r.iterate(it)
-            _, live = o.pathtrace(m, it, planes[(it - 1) % lanes])
+            _, live = acc.iteration(o, m, it)
             counts, _ = r.live_counts()
             assert np.array_equal(counts, live), (pipeline, it, counts, live)
         img = r.image(); r.close()
-        assert np.array_equal(img, planes[0] + planes[1]), pipeline
-    assert np.array_equal(planes[0] if False else _first_iteration(o, m), ref1)
+        assert np.array_equal(img, acc.img), pipeline
+    assert np.array_equal(_first_iteration(o, m), ref1)
 
 
 def _first_iteration(o, m):
@@ -254,16 +254,14 @@ def _sparse_tail(ptk, orc, name, res, depth, mode, lanes, pipeline):
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1, pipeline=pipeline)
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    acc = orc.Accumulator(o.P, lanes, 1, m)
     rays = 0
     for it in range(1, 13):
         r.iterate(it)
-        rr, live = o.pathtrace(m, it, planes[(it - 1) % lanes]); rays += rr
+        rr, live = acc.iteration(o, m, it); rays += rr
         counts, _ = r.live_counts()
         assert np.array_equal(counts, live), (it, counts, live)
-    ref = planes[0].copy()
-    for p in planes[1:]:
-        ref = ref + p
+    ref = acc.img
     img = r.image()
     assert r.ray_total() == rays
     # the camera launch's store placement (hits only, after the trace phase, in open scenes) is learnt the same way: both placements ran above
@@ -286,10 +284,10 @@ def test_sample_mode_switch_resets_the_tail_hint(ptk, orc, torch_cuda, lanes):
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, ptk.MODE_DIRECTLI, in_flight=lanes, graph=lanes > 1)
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    acc = orc.Accumulator(o.P, lanes, 1, ptk.MODE_DIRECTLI)          # (the policy is fixed at init: DIRECT -> ordered)
     it = 0
     for _ in range(12):
-        it += 1; r.iterate(it); o.pathtrace(ptk.MODE_DIRECTLI, it, planes[(it - 1) % lanes])
+        it += 1; r.iterate(it); acc.iteration(o, ptk.MODE_DIRECTLI, it)
         r.sync()
     assert r.full_width_bounces() == 1                      # DIRECT: counts[1] == 0, learnt within a few iterations
     assert ptk.lib.ptk_set_sample_mode(ptk.MODE_BSDF) == 0
@@ -297,13 +295,11 @@ def test_sample_mode_switch_resets_the_tail_hint(ptk, orc, torch_cuda, lanes):
         it += 1; r.iterate(it)
         if k == 0:
             assert r.full_width_bounces() == depth          # the first BSDF iteration is enqueued at full width again
-        _, live = o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+        _, live = acc.iteration(o, ptk.MODE_BSDF, it)
         counts, _ = r.live_counts()
         assert np.array_equal(counts, live), (it, counts, live)
     assert r.full_width_bounces() == depth                  # closed box: > 1024 paths alive at every bounce
-    ref = planes[0].copy()
-    for p in planes[1:]:
-        ref = ref + p
+    ref = acc.img
     img = r.image(); r.close()
     assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
@@ -315,14 +311,14 @@ def test_sparse_tail_with_partition_and_batches(ptk, orc, torch_cuda):
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, ptk.MODE_MIS, partition=part, spp=spp)
-    planes = np.zeros((spp, o.P, 3), np.float32)
+    acc = orc.Accumulator(o.P, 1, spp, ptk.MODE_MIS)
     for step in range(1, 13):
         r.iterate(step)
-        _, live = o.pathtrace_batch(ptk.MODE_MIS, step, spp, planes, partition=part)
+        _, live = acc.batch(o, ptk.MODE_MIS, step, partition=part)
         counts, _ = r.live_counts()
         assert np.array_equal(counts, live), (step, counts, live)
     img = r.image(); r.close()
-    assert np.array_equal(img, planes[0] + planes[1])
+    assert np.array_equal(img, acc.img)
 
 
 def test_intersect_edge_rays(ptk, orc, torch_cuda):
@@ -392,7 +388,7 @@ def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
 def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, flags, lanes):
     """The C++ pathtrace() only enqueues (no D2H, no host wait, SURVEY 8b "Outputs"); pathtraceResolve() makes scene->state.image and
     TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle, bit for bit — in the reference's order, with a
-    resolve after every call (--eager = pathtrace.cu:809-810) and with three iterations in flight + graph replay (ordered plane sum)."""
+    resolve after every call (--eager = pathtrace.cu:809-810) and with three iterations in flight + graph replay (MIS: the lanes' planes summed in order)."""
     import subprocess
     exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
     base = str(tmp_path / "lazy")
@@ -403,13 +399,10 @@ def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, flags, lanes):
     assert f"TracedDepth {D}" in r.stdout and "cpp_api {" in r.stdout
     img = np.fromfile(base + ".6samp.f32", np.float32).reshape(-1, 3)
     o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
-    planes = np.zeros((lanes, o.P, 3), np.float32)
+    acc = orc.Accumulator(o.P, lanes, 1, orc.MODE_MIS)
     for it in range(1, 7):
-        o.pathtrace(orc.MODE_MIS, it, planes[(it - 1) % lanes])
-    ref = planes[0].copy()
-    for l in range(1, lanes):
-        ref += planes[l]
-    assert np.array_equal(img, ref)
+        acc.iteration(o, orc.MODE_MIS, it)
+    assert np.array_equal(img, acc.img)
 
 
 def test_large_mesh_uploads_one_threaded_copy(ptk, torch_cuda):
@@ -535,20 +528,18 @@ def test_tonemap(ptk, orc, torch_cuda):
 def test_pathtrace_fills_the_pbo(ptk, orc, torch_cuda, lanes):
     """pathtrace(pbo, frame, iteration) with a device pbo (the viewer's call, main.cpp:212-219): after every call the pbo holds the
     display transform of the running sum divided by the iteration number (sendImageToPBO, pathtrace.cu:806), also when several
-    iterations are in flight (the planes are summed first).  +-1 LSB for powf; the radiance itself is compared exactly."""
+    iterations are in flight (every launch's plane merged in order first).  +-1 LSB for powf; the radiance itself is compared exactly — BSDF:
+    with three iterations in flight it is the SAME image as one at a time (ordered accumulation)."""
     torch = torch_cuda
     name, res, depth = "cornell.txt", (64, 48), 4
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes)
     pbo = torch.zeros((o.P, 4), dtype=torch.uint8, device="cuda")
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    ref_img = np.zeros((o.P, 3), np.float32)
     for it in (1, 2, 3, 4, 5):
         r.iterate(it, pbo=pbo)
-        o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
-        ref_img = planes[0].copy()
-        for p in planes[1:]:
-            ref_img = ref_img + p
+        o.pathtrace(ptk.MODE_BSDF, it, ref_img)
         r.sync()
         assert np.array_equal(r.image(), ref_img), (lanes, it)
         ref = np.zeros((o.P, 4), np.uint8); orc.L.orc_tonemap(ref_img.ctypes.data, o.P, it, ref.ctypes.data)
@@ -558,22 +549,22 @@ def test_pathtrace_fills_the_pbo(ptk, orc, torch_cuda, lanes):
 
 
 def test_pbo_without_host_sync(ptk, orc, torch_cuda):
-    """with iterations in flight, ptk_pathtrace(pbo) sums the planes on lane 0 asynchronously while the next call
-    may already write another lane's plane.  The lanes now wait for that sum (event edge).  Six calls with a pbo and NO host
-    synchronisation in between; after the last one the pbo is the display transform of the exact six-iteration sum."""
+    """with iterations in flight, ptk_pathtrace(pbo) tone-maps the image on lane 0 asynchronously while the next call's
+    merge (another lane's stream) may already add to it.  The lanes wait for that reader (event edge).  Six calls with a pbo and NO host
+    synchronisation in between; after the last one the pbo is the display transform of the exact six-iteration sum — BSDF: the
+    reference's own running sum."""
     torch = torch_cuda
     name, res, depth, lanes = "cornell.txt", (256, 256), 6, 3
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes, graph=True)
     pbo = torch.zeros((o.P, 4), dtype=torch.uint8, device="cuda")
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    ref_img = np.zeros((o.P, 3), np.float32)
     for it in range(1, 7):
         r.iterate(it, pbo=pbo)
     for it in range(1, 7):
-        o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+        o.pathtrace(ptk.MODE_BSDF, it, ref_img)
     r.sync()
-    ref_img = (planes[0] + planes[1]) + planes[2]
     assert np.array_equal(r.image(), ref_img)
     ref = np.zeros((o.P, 4), np.uint8); orc.L.orc_tonemap(ref_img.ctypes.data, o.P, 6, ref.ctypes.data)
     assert np.abs(pbo.cpu().numpy().astype(int) - ref.astype(int)).max() <= 1
@@ -609,26 +600,67 @@ def test_tile_partition(ptk, orc, torch_cuda):
 @pytest.mark.parametrize("name,res,depth,mode,lanes", [("cornell.txt", (128, 96), 5, "MIS", 3), ("bunny_cornell.txt", (96, 96), 4, "BSDF", 4),
                                                         ("mis_test.txt", (128, 128), 6, "MIS", 2)])
 def test_iterations_in_flight(ptk, orc, torch_cuda, name, res, depth, mode, lanes):
-    """L iterations in flight: every iteration is computed exactly as with L = 1 (same live counts per iteration), plane l
-    sums iterations l+1, l+1+L, ..., and the image is ((plane0 + plane1) + plane2) + ... — emulated with the oracle."""
+    """L iterations in flight: every iteration is computed exactly as with L = 1 (same live counts per iteration); the image follows the
+    accumulation policy of its sample mode (oracle_lib.Accumulator: BSDF ordered = the plain running sum, MIS the lanes' planes summed)."""
     m = MODES[mode]
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, m, in_flight=lanes)
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    acc = orc.Accumulator(o.P, lanes, 1, m)
     rays = 0
     for it in range(1, 2 * lanes + 2):
         r.iterate(it)
-        rr, live = o.pathtrace(m, it, planes[(it - 1) % lanes]); rays += rr
+        rr, live = acc.iteration(o, m, it); rays += rr
         counts, _ = r.live_counts()
         assert np.array_equal(counts, live), (it, counts, live)
-    ref = planes[0].copy()
-    for p in planes[1:]:
-        ref = ref + p
     img = r.image()
     assert r.ray_total() == rays
     r.close()
-    assert np.array_equal(img, ref)
+    assert np.array_equal(img, acc.img)
+
+
+@pytest.mark.parametrize("name,res,depth,mode", [("cornell.txt", (200, 160), 8, "BSDF"), ("mis_test.txt", (200, 160), 8, "DIRECT"), ("bunny_cornell.txt", (96, 96), 6, "BSDF"),
+                                                 ("mis_test.txt", (160, 160), 10, "BSDF"), ("textureEnv_test.txt", (128, 128), 6, "BSDF")])
+def test_iterations_in_flight_keep_the_reference_order(ptk, orc, torch_cuda, name, res, depth, mode):
+    """ORDERED ACCUMULATION (round 4).  In BSDF and DIRECT mode a pixel receives at most one add per iteration (pathtrace.cu:398,486 and the
+    ENV add of :303-311), so with every launch's plane folded into the image in iteration order the image of THREE ITERATIONS IN FLIGHT +
+    graph replay — the configuration bench.py's headline is timed in — is the reference's own running sum (pathtrace.cu:600): bit-identical to
+    one iteration at a time and to the oracle's plain sequential render, eleven iterations (incl. the k_tail regime and the ENV adds)."""
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    seq = np.zeros((o.P, 3), np.float32)
+    for it in range(1, 12):
+        o.pathtrace(m, it, seq)
+    o.close()
+    assert seq.sum() > 0
+    imgs = {}
+    for lanes in (1, 3):
+        r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
+        for it in range(1, 12):
+            r.iterate(it)
+        imgs[lanes] = r.image(); r.close()
+    assert np.array_equal(imgs[1], seq), int((imgs[1] != seq).any(axis=1).sum())
+    assert np.array_equal(imgs[3], seq), int((imgs[3] != seq).any(axis=1).sum())
+
+
+@pytest.mark.parametrize("mode,ordered", [("MIS", 1), ("BSDF", 0), ("MIS", 0)])
+def test_accumulation_policy_can_be_forced(ptk, orc, torch_cuda, mode, ordered):
+    """ptk_set_ordered_accumulation(1 / 0) against the default (ordered unless MIS): MIS with every iteration's plane folded in order, BSDF with
+    planes that accumulate — three iterations in flight + graph replay, eight iterations == the oracle's restatement of that policy."""
+    name, res, depth, lanes = "cornell.txt", (128, 96), 6, 3
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, in_flight=lanes, graph=True, ordered=ordered)
+    acc = orc.Accumulator(o.P, lanes, 1, m, ordered=bool(ordered))
+    for it in range(1, 9):
+        r.iterate(it); acc.iteration(o, m, it)
+    img = r.image(); r.close()
+    assert np.array_equal(img, acc.img), int((img != acc.img).any(axis=1).sum())
+    with pytest.raises(ptk.PtkError):
+        ptk.Renderer(s, m, ordered=2)
+    ptk.lib.ptk_set_ordered_accumulation(-1)
 
 
 TILE_CASES = [  # scene, res, depth, mode, tiles, graph replay
@@ -714,23 +746,21 @@ def test_tiles_in_flight_refuses_what_it_cannot_do(ptk, torch_cuda):
     ("bunny_cornell.txt", (64, 64), 4, "BSDF", 3, (3, 2, 4), 2),    # ... with iterations in flight on top
 ])
 def test_samples_per_launch(ptk, orc, torch_cuda, name, res, depth, mode, spp, part, lanes):
-    """spp iterations of the owned pixels traced in one set of launches, one radiance plane per sample, against the oracle's
-    restatement of the same batching (sample-major path order, per-iteration camera keys, batch-keyed shading RNG)."""
+    """spp iterations of the owned pixels traced in one set of launches, one radiance plane per sample (folded into the image in sample order
+    when the launch is done), against the oracle's restatement of the same batching (sample-major path order, per-iteration camera keys,
+    batch-keyed shading RNG)."""
     m = MODES[mode]
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, m, partition=part, in_flight=lanes, spp=spp)
-    planes = np.zeros((lanes, spp, o.P, 3), np.float32)
+    acc = orc.Accumulator(o.P, lanes, spp, m)
     rays = 0
     for step in range(1, 2 * lanes + 2):
         r.iterate(step)
-        rr, live = o.pathtrace_batch(m, step, spp, planes[(step - 1) % lanes], partition=part); rays += rr
+        rr, live = acc.batch(o, m, step, partition=part); rays += rr
         counts, _ = r.live_counts()
         assert np.array_equal(counts, live), (step, counts, live)
-    flat = planes.reshape(lanes * spp, o.P, 3)
-    ref = flat[0].copy()
-    for p in flat[1:]:
-        ref = ref + p
+    ref = acc.img
     img = r.image()
     assert r.ray_total() == rays
     r.close()
@@ -746,17 +776,15 @@ def test_graph_replay(ptk, orc, torch_cuda):
         s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
         o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
         r = ptk.Renderer(s, ptk.MODE_MIS, in_flight=lanes, graph=True)
-        planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+        acc = orc.Accumulator(o.P, lanes, 1, ptk.MODE_MIS)          # (the policy is fixed at init: MIS -> planes that accumulate)
         seq = [(it, ptk.MODE_MIS) for it in (1, 2, 3, 4, 5, 6, 7)] + [(20, ptk.MODE_MIS), (21, ptk.MODE_BSDF), (22, ptk.MODE_BSDF), (23, ptk.MODE_BSDF)]
         for it, mode in seq:
             ptk.lib.ptk_set_sample_mode(mode)
             r.iterate(it)
-            _, live = o.pathtrace(mode, it, planes[(it - 1) % lanes])
+            _, live = acc.iteration(o, mode, it)
             counts, _ = r.live_counts()
             assert np.array_equal(counts, live), (lanes, it, counts, live)
-        ref = planes[0].copy()
-        for p in planes[1:]:
-            ref = ref + p
+        ref = acc.img
         img = r.image(); r.close()
         assert np.array_equal(img, ref), lanes
 
@@ -834,24 +862,24 @@ def test_reference_scene_without_camera_is_refused(ptk, torch_cuda):
 
 def test_benchmarked_configuration_full_size(ptk, orc, torch_cuda):
     """What bench.py times by default: cornell.txt 800x800 depth 8, BSDF, THREE iterations in flight + hipGraph
-    replay, six iterations (every lane replays its graph): per-iteration live counts == oracle, image == the oracle's three
-    planes summed in lane order ((p0 + p1) + p2), bit for bit."""
+    replay, six iterations (every lane replays its graph): per-iteration live counts == oracle, image == the oracle's PLAIN SEQUENTIAL
+    render — the reference's own running sum (ordered accumulation: BSDF adds once per pixel and iteration) — bit for bit."""
     name, lanes = "cornell.txt", 3
     s = ptk.Scene(os.path.join(SC, name)); o = orc.Scene(os.path.join(SC, name))
     assert (s.width, s.height, s.trace_depth) == (800, 800, 8)
     r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes, graph=True)
-    planes = [np.zeros((o.P, 3), np.float32) for _ in range(lanes)]
+    ref = np.zeros((o.P, 3), np.float32)
     orc.set_threads(host_threads())
     try:
         for it in range(1, 7):
             r.iterate(it)
-            _, live = o.pathtrace(ptk.MODE_BSDF, it, planes[(it - 1) % lanes])
+            _, live = o.pathtrace(ptk.MODE_BSDF, it, ref)
             counts, _ = r.live_counts()
             assert np.array_equal(counts, live), (it, counts, live)
     finally:
         orc.set_threads(1)
     img = r.image(); r.close()
-    assert np.array_equal(img, (planes[0] + planes[1]) + planes[2])
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
 
 def test_configs4_tile_part_full_size(ptk, orc, torch_cuda):
@@ -1020,10 +1048,10 @@ def test_fixed_cube_lights(ptk, orc, torch_cuda, mode):
         r = ptk.Renderer(s, m, in_flight=2, graph=True)
         for it in (1, 2, 3, 4):
             r.iterate(it)
-        planes = [np.zeros((o.P, 3), np.float32) for _ in range(2)]
+        acc = orc.Accumulator(o.P, 2, 1, m)
         for it in (1, 2, 3, 4):
-            o.pathtrace(m, it, planes[(it - 1) % 2])
-        ref = planes[0] + planes[1]
+            acc.iteration(o, m, it)
+        ref = acc.img
         img = r.image(); r.close()
         assert np.array_equal(img, ref)
         fixed_sum = float(ref.sum())

@@ -12,7 +12,7 @@ a = sys.argv[1].split(",")
 scn, mode = a[0], int(a[1]); lanes = int(a[2]) if len(a) > 2 else 3; pipe = int(a[3]) if len(a) > 3 else 0
 res = (int(a[4]), int(a[5])) if len(a) > 5 and int(a[4]) > 0 else None; depth = int(a[6]) if len(a) > 6 else -1; tiles = int(a[7]) if len(a) > 7 else 1
 s = ptk.Scene(os.path.join(%r, "scenes", scn), res=res, depth=depth)
-r = ptk.Renderer(s, mode, pipeline=pipe, in_flight=lanes, graph=lanes > 1 or tiles > 1, tiles=tiles)
+r = ptk.Renderer(s, mode, pipeline=pipe, in_flight=lanes, graph=lanes > 1 or tiles > 1, tiles=tiles, ordered=int(os.environ.get('AB_ORDERED', '-1')))      # AB_ORDERED: ptk_set_ordered_accumulation
 n = 96 if s.width * s.height <= 1000000 else 32
 for it in range(1, 33): r.iterate(it)
 r.sync(); r0 = r.ray_total(); r.timer_start()

@@ -70,17 +70,15 @@ def one_case(seed, tmp):
     kw = dict(in_flight=lanes, graph=graph or tiles > 1, pipeline=pipeline, tiles=tiles)
     if part[0] > 1: kw.update(partition=part, spp=spp)
     r = ptk.Renderer(s, mode, **kw)
-    planes = np.zeros((lanes, spp, o.P, 3), np.float32)
+    acc = orc.Accumulator(o.P, lanes, spp, mode)          # the product's accumulation policy (ordered unless MIS)
     for it in range(1, iters + 1):
         r.iterate(it)
-        if part[0] > 1: _, live = o.pathtrace_batch(mode, it, spp, planes[(it - 1) % lanes], partition=part)
-        else: _, live = o.pathtrace(mode, it, planes[(it - 1) % lanes][0])
+        if part[0] > 1: _, live = acc.batch(o, mode, it, partition=part)
+        else: _, live = acc.iteration(o, mode, it)
         if it % 3 == 0 or it == iters:
             counts, _ = r.live_counts()
             assert np.array_equal(counts, live), (seed, it, counts, live)
-    flat = planes.reshape(lanes * spp, o.P, 3)
-    ref = flat[0].copy()
-    for p in flat[1:]: ref = ref + p
+    ref = acc.img
     img = r.image(); r.close(); s.close(); o.close()
     bad = int((img != ref).any(axis=1).sum())
     return bad, info, dict(mode=mode, lanes=lanes, tiles=tiles, graph=graph, part=part, spp=spp, pipeline=pipeline, iters=iters, lit=float(ref.sum()))
