@@ -537,8 +537,9 @@ def main():
         if N == 1 and not a.lean and os.path.exists(exe):
             # the drop-in C++ API (pathtraceInit / pathtrace / pathtraceFree of src/pathtrace.h:6-9, csrc/pathtrace.h) driven by the headless replay of
             # main.cpp's loop, own process: wall time of the pathtrace() calls + ONE pathtraceResolve() (the host image for saveImage), SURVEY 8(d)'s
-            # definition of the metric.  `value`: the API's defaults (one iteration at a time = the reference's accumulation order); `overlapped`: the
-            # same calls with PTK-side knobs 3 in flight + graph replay; `eager`: a host image after EVERY call like pathtrace.cu:809-810
+            # definition of the metric.  `value`: the API's defaults — in BSDF / DIRECT mode three iterations in flight + graph replay with ordered
+            # accumulation (image bit-identical to one iteration at a time), in MIS one iteration at a time; `one_at_a_time`: --in-flight 1 --graph 0, the
+            # reference's own schedule; `overlapped`: the knobs set explicitly; `eager`: a host image after EVERY call like pathtrace.cu:809-810
             import subprocess
             def headless(*flags):
                 c = subprocess.run([exe, scene_path, "--mode", a.mode, "--iters", str((a.warmup + a.steps) * IPS), "--warmup", str(a.warmup * IPS), "--no-save", *flags]
@@ -548,9 +549,11 @@ def main():
                 return {"value": round(j["rays"] / j["seconds"] / 1e6, 3), "ms_per_iteration": round(1e3 * j["seconds"] / j["iterations"], 4)}
             try:
                 cpp_api = dict(headless(), unit="Mrays/s",
-                               config="csrc/ptk_headless: pathtraceInit + %d x pathtrace(nullptr, 0, it) + pathtraceResolve(), API defaults (one iteration at a time)" % (a.steps * IPS),
+                               config=("csrc/ptk_headless: pathtraceInit + %d x pathtrace(nullptr, 0, it) + pathtraceResolve(), API defaults (" % (a.steps * IPS))
+                                      + ("one iteration at a time)" if a.mode == "mis" else "BSDF / DIRECT: 3 iterations in flight + graph replay, ordered accumulation = the reference's running sum, bit-identical image)"),
+                               one_at_a_time=headless("--in-flight", "1", "--graph", "0"),
                                overlapped=headless("--in-flight", str(a.in_flight), "--graph", str(a.graph)),
-                               eager=headless("--eager"),
+                               eager=headless("--in-flight", "1", "--graph", "0", "--eager"),
                                eager_note="a resolve (7.7 MB D2H + host wait) after every call = what the reference's pathtrace() does (pathtrace.cu:809-810)")
             except Exception as e:
                 cpp_api = {"error": str(e)[:200]}

@@ -10,7 +10,8 @@
 //        [--warmup W] [--no-save] [--in-flight L] [--tiles K] [--graph 0|1] [--eager]
 // Timing (bench.py `cpp_api`): --warmup W renders W untimed iterations first (then waits for the GPU); the timed region is the remaining
 // pathtrace() calls plus ONE pathtraceResolve() — what a viewer that saves the image at the end pays.  --eager resolves after every call
-// (the reference's pathtrace.cu:809-810 behaviour), --in-flight / --graph are the ptk_set_* knobs (defaults 1 / 0: the reference's order).
+// (the reference's pathtrace.cu:809-810 behaviour), --in-flight / --tiles / --graph are the ptk_set_* knobs; without them pathtraceInit chooses
+// (BSDF / DIRECT: 3 in flight + graph replay, image bit-identical to one at a time; MIS: one at a time — pathtrace.hip).
 #include "pathtrace.h"
 #include <chrono>
 #include <cmath>

@@ -72,6 +72,7 @@ struct RenderContext {
     hipEvent_t resolved = nullptr;      // recorded on lane 0 after an asynchronous reader of the image (ptk_pathtrace's tone map)
     float* planes = nullptr;            // float[L][spp][3*P]
     float* image = nullptr;             // float[3*P]: the running sum, in iteration order (== planes when there is one plane)
+    bool sched_explicit = false;        // ptk_set_iterations_in_flight / _tiles_in_flight / _graph_replay was called: pathtraceInit keeps the caller's schedule
     int want_ordered = -1;              // ptk_set_ordered_accumulation: -1 auto (ordered unless the sample mode at ptk_pathtrace_init is MIS), 0, 1
     bool ordered = false;               // several planes AND ordered accumulation (merge_lane); false: the planes accumulate, resolve_image sums them
     hipEvent_t last_merged = nullptr;   // ordered accumulation: the event of the latest merge (some lane's `merged`), nullptr before the first
@@ -628,7 +629,7 @@ int ptk_get_sample_mode(void) { return current_mode(); }
  * the default's. */
 int ptk_set_tiles_in_flight(int tiles) {
     if (tiles < 1 || tiles > kMaxLanes || g.live) return PTK_E_BADARG;
-    g.want_tiles = tiles;
+    g.want_tiles = tiles; g.sched_explicit = true;
     return 0;
 }
 /* Accumulation with several radiance planes (iterations in flight, samples per launch; set before ptk_pathtrace_init): 1 = ordered — every
@@ -642,7 +643,7 @@ int ptk_set_ordered_accumulation(int on) {
 }
 int ptk_set_iterations_in_flight(int lanes) {
     if (lanes < 1 || lanes > kMaxLanes || g.live) return PTK_E_BADARG;     // set before ptk_pathtrace_init
-    g.n_lanes = lanes;
+    g.n_lanes = lanes; g.sched_explicit = true;
     return 0;
 }
 
@@ -660,7 +661,7 @@ static int need_six_copies() {
 /* Opt-in fixed cube lights (not reference behaviour, default off): cube lights get a sampled position and a pdf. */
 int ptk_set_light_fix(int on) { set_light_fix(on != 0); invalidate_graphs(); return 0; }
 /* Replay each iteration from a captured hipGraph (1) instead of launching its ~25 kernels one by one (0, default). */
-int ptk_set_graph_replay(int on) { g.use_graph = on != 0; return 0; }
+int ptk_set_graph_replay(int on) { g.use_graph = on != 0; g.sched_explicit = true; return 0; }
 
 /* Samples per launch (1..64, default 1; set before ptk_pathtrace_init): ptk_pathtrace(.., step) then traces iterations
  * (step-1)*spp + 1 .. step*spp of the owned pixels in ONE set of launches (camera jitter keyed per iteration as usual, shading
@@ -872,12 +873,20 @@ int ptk_timer_stop(float* ms) {
 // ---------------------------------------------------------------- C++ API (pathtrace.h)
 void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
-// Knobs of the C++ API, read at pathtraceInit (the four reference signatures have no room for them): PTK_IN_FLIGHT=<L> iterations in flight,
-// PTK_TILES=<K> tiles in flight (bit-identical image; wants PTK_GRAPH=1), PTK_GRAPH=1 hipGraph replay, PTK_ORDERED=-1|0|1 accumulation with several
-// planes (all as ptk_set_*; defaults 1 / 1 / 0 / -1 = the reference's accumulation order), PTK_EAGER_IMAGE=1 = refresh
+// Schedule of the C++ API, chosen at pathtraceInit (the four reference signatures have no room for knobs).  DEFAULT: in BSDF / DIRECT mode three
+// iterations in flight + hipGraph replay with ordered accumulation — scene->state.image is bit-identical to one iteration at a time, i.e. to the
+// reference's running sum (merge_lane) — and one iteration at a time in MIS (whose bounce-by-bounce adds no overlap of whole iterations
+// reproduces; PTK_TILES=3 is the bit-identical overlap there).  The viewer re-initialises on a sample-mode change (main.cpp:173-201,
+// preview.cpp:247), so the choice follows the mode.  Overrides: PTK_IN_FLIGHT=<L>, PTK_TILES=<K>, PTK_GRAPH=0|1, PTK_ORDERED=-1|0|1 (as the
+// ptk_set_* calls, which a host may also make itself before pathtraceInit), PTK_EAGER_IMAGE=1 = refresh
 // scene->state.image after EVERY call like pathtrace.cu:809-810 (a 7.7 MB D2H and a host wait per 0.3 ms iteration at 800 x 800).
 void pathtraceInit(Scene* scene) {
     if (!g.live) {
+        const bool env_sched = getenv("PTK_IN_FLIGHT") || getenv("PTK_TILES") || getenv("PTK_GRAPH");
+        if (!g.sched_explicit && !env_sched) {
+            const bool overlap = current_mode() != PTK_MODE_MIS;
+            g.n_lanes = overlap ? 3 : 1; g.use_graph = overlap; g.want_tiles = 1;
+        }
         if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.n_lanes = l; }
         if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;
         if (const char* e = getenv("PTK_TILES")) { const int t = atoi(e); if (t >= 1 && t <= kMaxLanes) g.want_tiles = t; }

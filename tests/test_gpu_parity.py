@@ -384,25 +384,38 @@ def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
     assert png.shape == (48, 64, 3) and np.array_equal(png, pix)
 
 
-@pytest.mark.parametrize("flags,lanes", [((), 1), (("--eager",), 1), (("--in-flight", "3", "--graph", "1"), 3)])
-def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, flags, lanes):
+@pytest.mark.parametrize("mode,flags,lanes", [("mis", (), 1), ("mis", ("--eager",), 1), ("mis", ("--in-flight", "3", "--graph", "1"), 3),
+                                              ("bsdf", (), 3), ("bsdf", ("--in-flight", "1", "--graph", "0"), 1), ("direct", (), 3)])
+def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, mode, flags, lanes):
     """The C++ pathtrace() only enqueues (no D2H, no host wait, SURVEY 8b "Outputs"); pathtraceResolve() makes scene->state.image and
-    TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle, bit for bit — in the reference's order, with a
-    resolve after every call (--eager = pathtrace.cu:809-810) and with three iterations in flight + graph replay (MIS: the lanes' planes summed in order)."""
+    TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle, bit for bit — MIS at the defaults (one iteration at a
+    time: the reference's order), with a resolve after every call (--eager = pathtrace.cu:809-810) and with three iterations in flight + graph
+    replay (the lanes' planes summed in order); BSDF / DIRECT at the defaults (three iterations in flight + graph replay, ordered accumulation)
+    == the oracle's PLAIN SEQUENTIAL render == the explicit one-at-a-time schedule."""
     import subprocess
     exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
     base = str(tmp_path / "lazy")
     W, H, D = 200, 160, 5
-    cmd = [exe, os.path.join(SC, "cornell.txt"), "--mode", "mis", "--iters", "6", "--res", str(W), str(H), "--depth", str(D), "--out", base, *flags]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+    scene = "cornell.txt" if mode != "direct" else "mis_test.txt"          # (cornell's cube light gives DIRECT nothing, lightSample.h:141-248)
+    cmd = [exe, os.path.join(SC, scene), "--mode", mode, "--iters", "6", "--res", str(W), str(H), "--depth", str(D), "--out", base, *flags]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PTK_")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert f"TracedDepth {D}" in r.stdout and "cpp_api {" in r.stdout
+    assert "cpp_api {" in r.stdout and (mode == "direct" or f"TracedDepth {D}" in r.stdout)
     img = np.fromfile(base + ".6samp.f32", np.float32).reshape(-1, 3)
-    o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
-    acc = orc.Accumulator(o.P, lanes, 1, orc.MODE_MIS)
-    for it in range(1, 7):
-        acc.iteration(o, orc.MODE_MIS, it)
-    assert np.array_equal(img, acc.img)
+    o = orc.Scene(os.path.join(SC, scene), res=(W, H), depth=D)
+    m = {"mis": orc.MODE_MIS, "bsdf": orc.MODE_BSDF, "direct": orc.MODE_DIRECTLI}[mode]
+    if mode == "mis":
+        acc = orc.Accumulator(o.P, lanes, 1, m)
+        for it in range(1, 7):
+            acc.iteration(o, m, it)
+        ref = acc.img
+    else:
+        ref = np.zeros((o.P, 3), np.float32)
+        for it in range(1, 7):
+            o.pathtrace(m, it, ref)
+    assert ref.sum() > 0
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
 
 def test_large_mesh_uploads_one_threaded_copy(ptk, torch_cuda):
