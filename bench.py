@@ -495,8 +495,8 @@ def main():
         ref_order = None
         if N == 1 and not a.lean and (a.in_flight != 1 or a.graph):
             # the reference's own schedule: one iteration at a time, eager launches.  (The headline overlaps `in_flight` iterations, each computed
-            # unchanged into its own plane and folded into the image in iteration order: in BSDF / DIRECT mode — this workload — the image is
-            # bit-identical to this schedule's, tests/test_gpu_parity.py::test_iterations_in_flight_keep_the_reference_order; MIS: float association differs)
+            # unchanged into its own planes, which are folded into the image in the reference's order of adds: the image is bit-identical to this
+            # schedule's in every sample mode, tests/test_gpu_parity.py::test_iterations_in_flight_keep_the_reference_order)
             rr = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=1, graph=False)
             for i in range(1, a.warmup * IPS + 1):
                 rr.iterate(i)
@@ -519,7 +519,7 @@ def main():
             rt.close()
             ref_order["tiles_in_flight"] = {"value": round(qr / tt / 1e6, 3), "unit": "Mrays/s", "ms_per_iteration": round(1e3 * tt / (a.steps * IPS), 4),
                                             "config": "tiles_in_flight 3, graph_replay true: the reference's accumulation order and RNG keys, bit-identical image (tests/test_gpu_parity.py::test_tiles_in_flight*)"}
-        if ref_order is not None and a.tiles <= 1 and a.in_flight > 1 and a.mode != "mis":
+        if ref_order is not None and a.tiles <= 1 and a.in_flight > 1:
             # what the ordered accumulation costs: the headline's configuration with planes that accumulate instead (ptk_set_ordered_accumulation(0):
             # image = ((p0 + p1) + p2), float association differs from the reference's) — rounds 2 and 3 timed THIS form
             ru = ptk.Renderer(scene, mode, pipeline=a.pipeline, in_flight=a.in_flight, graph=bool(a.graph), ordered=0)
@@ -537,8 +537,8 @@ def main():
         if N == 1 and not a.lean and os.path.exists(exe):
             # the drop-in C++ API (pathtraceInit / pathtrace / pathtraceFree of src/pathtrace.h:6-9, csrc/pathtrace.h) driven by the headless replay of
             # main.cpp's loop, own process: wall time of the pathtrace() calls + ONE pathtraceResolve() (the host image for saveImage), SURVEY 8(d)'s
-            # definition of the metric.  `value`: the API's defaults — in BSDF / DIRECT mode three iterations in flight + graph replay with ordered
-            # accumulation (image bit-identical to one iteration at a time), in MIS one iteration at a time; `one_at_a_time`: --in-flight 1 --graph 0, the
+            # definition of the metric.  `value`: the API's defaults — three iterations in flight + graph replay with ordered accumulation (image
+            # bit-identical to one iteration at a time); `one_at_a_time`: --in-flight 1 --graph 0, the
             # reference's own schedule; `overlapped`: the knobs set explicitly; `eager`: a host image after EVERY call like pathtrace.cu:809-810
             import subprocess
             def headless(*flags):
@@ -550,7 +550,7 @@ def main():
             try:
                 cpp_api = dict(headless(), unit="Mrays/s",
                                config=("csrc/ptk_headless: pathtraceInit + %d x pathtrace(nullptr, 0, it) + pathtraceResolve(), API defaults (" % (a.steps * IPS))
-                                      + ("one iteration at a time)" if a.mode == "mis" else "BSDF / DIRECT: 3 iterations in flight + graph replay, ordered accumulation = the reference's running sum, bit-identical image)"),
+                                      + "3 iterations in flight + graph replay, ordered accumulation = the reference's running sum, bit-identical image)",
                                one_at_a_time=headless("--in-flight", "1", "--graph", "0"),
                                overlapped=headless("--in-flight", str(a.in_flight), "--graph", str(a.graph)),
                                eager=headless("--in-flight", "1", "--graph", "0", "--eager"),
@@ -596,9 +596,9 @@ def main():
                        "iterations_total": head["calls"] * (N if a.shard == "iterations" else 1) * spp,
                        "iterations_in_flight": a.in_flight if a.tiles <= 1 else 1, "tiles_in_flight": max(a.tiles, 1), "graph_replay": bool(a.graph),
                        "accumulation": ("in place: the reference's own order" if (a.in_flight <= 1 and spp <= 1) or a.tiles > 1 else
-                                        ("ordered: every iteration's plane is folded into the image in iteration order (one k_merge_planes launch per iteration, inside the "
-                                         "timed region); BSDF / DIRECT add once per pixel and iteration: the image is bit-identical to one iteration at a time (reference_order)")
-                                        if a.mode != "mis" else "planes accumulate (MIS adds bounce by bounce: no order of whole iterations is bit-identical), summed when the image is read"),
+                                        "ordered: every iteration adds into planes of its own (one; one per bounce in MIS) that are folded into the image in the reference's "
+                                        "order of adds (one k_merge_planes launch per iteration, inside the timed region): the image is bit-identical to one iteration at a "
+                                        "time (reference_order)" + ("" if spp <= 1 or a.mode != "mis" else " — except MIS with samples per launch: one plane per sample")),
                        "pipeline": ("one launch per bounce: k_shade_trace shades bounce d-1 and traces bounce d (segmented streams, physical-slot hit records, window hit "
                                     "prefixes); device-resident counts, no host sync") if fused else
                                    "per bounce: intersect stage / shade with block-local compaction / window prefix (segmented streams); device-resident counts, no host sync",

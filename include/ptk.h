@@ -170,18 +170,18 @@ int ptk_get_sample_mode(void);
  * image is BIT-IDENTICAL to the default's, i.e. to the reference's own accumulation order (pathtrace.cu:697-810). */
 int ptk_set_tiles_in_flight(int tiles);
 /* Iterations in flight (1..16, default 1; set before ptk_pathtrace_init).  With L > 1, the call `step` runs on lane
- * (step-1) % L (own stream, buffers and radiance plane), so consecutive ptk_pathtrace calls overlap on the GPU.  Every
- * iteration is computed exactly as with L = 1 into its lane's plane — zero when it starts — and the plane is folded into the
- * image when the iteration is done, IN CALL ORDER (ordered accumulation): image = ((image + it_1) + it_2) + ..., the
- * reference's running sum (pathtrace.cu:600).  BSDF and DIRECT add at most once per pixel and iteration (pathtrace.cu:398,486,
- * 303-311), so there the image is BIT-IDENTICAL to one iteration at a time; MIS adds its next-event terms bounce by bounce
- * (pathtrace.cu:556,572): no order of whole iterations reproduces that sum, so by default MIS keeps the cheaper form
- * (ptk_set_ordered_accumulation below; use ptk_set_tiles_in_flight for a bit-identical MIS image).  Not a reference feature. */
+ * (step-1) % L (own stream, buffers and radiance planes), so consecutive ptk_pathtrace calls overlap on the GPU.  Every
+ * iteration is computed exactly as with L = 1 into its lane's planes — zero when it starts; one plane, or one per bounce when
+ * the context is initialised in MIS mode, so that every (pixel, plane) receives at most one add (pathtrace.cu:398,486,556,572,
+ * 303-311) — and the planes are folded into the image when the iteration is done, in call order and bounce by bounce (ordered
+ * accumulation): image = ((image + a_1) + a_2) + ..., the reference's own sequence of adds (pathtrace.cu:600).  The image is
+ * BIT-IDENTICAL to one iteration at a time in every sample mode.  Not a reference feature. */
 int ptk_set_iterations_in_flight(int lanes);
 /* Accumulation policy with several radiance planes (L iterations in flight and / or S samples per launch; set before ptk_pathtrace_init).
- * 1: ordered, as described above (one small merge launch per call; measured -3 % on cornell.txt BSDF, -9 % on mis_test.txt 1024 x 1024).
- * 0: the planes accumulate — plane l sums the calls l+1, l+1+L, ... — and are summed when the image is read: ((plane0 + plane1) + plane2) + ...
- * -1 (default): ordered unless the sample mode at ptk_pathtrace_init is MIS, where no order makes the image bit-identical. */
+ * -1 / 1 (default): ordered, as described above (one small merge launch per call; measured -3 % on cornell.txt BSDF, -5 % MIS, -7..-10 % on the
+ * short iterations of mis_test.txt 1024 x 1024).  Not bit-identical to one iteration at a time, though valid: MIS with samples per launch (one plane
+ * per sample) and MIS after ptk_set_sample_mode on a context initialised in another mode (one plane; re-initialise instead).
+ * 0: the planes accumulate — plane l sums the calls l+1, l+1+L, ... — and are summed when the image is read: ((plane0 + plane1) + plane2) + ... */
 int ptk_set_ordered_accumulation(int on);
 /* Samples per launch (1..64, default 1; set before ptk_pathtrace_init).  With spp > 1, ptk_pathtrace(.., step) traces
  * iterations (step-1)*spp + 1 .. step*spp of the owned pixels in one set of launches: camera jitter is keyed per iteration

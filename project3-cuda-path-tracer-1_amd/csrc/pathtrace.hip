@@ -37,7 +37,8 @@ struct Lane {
     PtkHits hits = {nullptr, nullptr, nullptr}, hitsB = {nullptr, nullptr, nullptr};     // hitsB, hrA/hrB: fused pipeline (hit records ping-pong with the paths)
     int* hrA = nullptr; int* hrB = nullptr;
     Workspace ws;
-    float* plane = nullptr;             // float[spp][3*P]: the radiance of the launch in flight on this lane, merged into the image when it is done (merge_lane); the image itself with one lane, one sample per launch or tiles in flight
+    float* plane = nullptr;             // float[spp][n_depth][3*P]: the radiance of the launch in flight on this lane, merged into the image when it is done (merge_lane); the image itself with one lane, one sample per launch or tiles in flight
+    unsigned char* flags = nullptr;     // touched-tile flags of those planes (ordered accumulation), [spp][n_depth][ceil(P / 64)]
     int last_iter = 0;
     // hipGraph replay of one iteration (all launches of render_iteration): the iteration number lives on the device
     int* iter_dev = nullptr;
@@ -75,6 +76,8 @@ struct RenderContext {
     bool sched_explicit = false;        // ptk_set_iterations_in_flight / _tiles_in_flight / _graph_replay was called: pathtraceInit keeps the caller's schedule
     int want_ordered = -1;              // ptk_set_ordered_accumulation: -1 auto (ordered unless the sample mode at ptk_pathtrace_init is MIS), 0, 1
     bool ordered = false;               // several planes AND ordered accumulation (merge_lane); false: the planes accumulate, resolve_image sums them
+    int n_depth = 1;                    // planes per sample: traceDepth + 1 (one per bounce) with ordered accumulation initialised in MIS mode, else 1
+    unsigned char* flags = nullptr;     // [L][spp][n_depth][ceil(P / 64)] (ordered accumulation), else null
     hipEvent_t last_merged = nullptr;   // ordered accumulation: the event of the latest merge (some lane's `merged`), nullptr before the first
     unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
@@ -137,11 +140,11 @@ int context_free() {
     if (g.host_image_reg) { (void)hipHostUnregister(g.host_image_reg); g.host_image_reg = nullptr; }
     if (g.image != g.planes) dfree(g.image);
     g.image = nullptr;
-    dfree(g.planes); dfree(g.ray_total);
+    dfree(g.planes); dfree(g.flags); dfree(g.ray_total);
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
     if (g.resolved) { (void)hipEventDestroy(g.resolved); g.resolved = nullptr; }
-    g.last_merged = nullptr; g.ordered = false;
+    g.last_merged = nullptr; g.ordered = false; g.n_depth = 1;
     g.live = false; g.tiles = false; g.scene = nullptr; g.P = g.capacity = 0;
     return 0;
 }
@@ -204,7 +207,8 @@ int lane_init(Lane& l, int idx) {
         for (hipEvent_t& ev : l.ring_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
     } else {
         l.n_parts = g.n_parts; l.part = g.part; l.tile_rows = g.tile_rows;
-        l.plane = g.planes + (size_t)idx * g.spp * 3 * (size_t)g.P;
+        l.plane = g.planes + (size_t)idx * g.spp * g.n_depth * 3 * (size_t)g.P;
+        l.flags = g.flags ? g.flags + (size_t)idx * g.spp * g.n_depth * ((g.P + 63) / 64) : nullptr;
         // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
         l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;          // fits an int: checked in context_init
     }
@@ -212,7 +216,12 @@ int lane_init(Lane& l, int idx) {
     l.capacity = l.n_pix * g.spp;
     l.full_bounces = g.traceDepth;                  // until live counts of earlier iterations say otherwise (note_counts)
     l.gen_late = 0;
-    l.ws.plane_stride = g.spp > 1 ? 3u * (unsigned)g.P : 0u;      // 0: no sample-plane bits in pixelIndex (pixel_ptr, ptk_kernels.hip)
+    l.ws.plane_stride = g.spp > 1 ? (unsigned)g.n_depth * 3u * (unsigned)g.P : 0u;      // 0: no sample-plane bits in pixelIndex (film_add, ptk_kernels.hip)
+    if (!g.tiles) {
+        const unsigned tiles = (unsigned)((g.P + 63) / 64);
+        l.ws.depth_stride = g.n_depth > 1 ? 3u * (unsigned)g.P : 0u;
+        l.ws.film_flags = l.flags; l.ws.flag_sample_stride = (unsigned)g.n_depth * tiles; l.ws.flag_depth_stride = g.n_depth > 1 ? tiles : 0u;
+    }
     l.ws.spp = g.spp;
     if ((rc = alloc_paths(l.bufA, l.capacity))) return rc;
     if ((rc = alloc_paths(l.bufB, l.capacity))) return rc;
@@ -292,14 +301,24 @@ int context_init(Scene* scene) {
         if (g.n_lanes < 2) { g.tiles = false; g.n_lanes = 1; }
     }
     const size_t plane = 3 * (size_t)g.P;
-    const size_t n_planes = g.tiles ? 1 : (size_t)g.n_lanes * g.spp;
+    // Accumulation (merge_lane): with several planes the default is ORDERED — one plane per sample and, when the context is initialised in MIS mode,
+    // per bounce, so that every (pixel, plane) receives one add and the merge can repeat the reference's own sequence of adds
+    const size_t n_basic = g.tiles ? 1 : (size_t)g.n_lanes * g.spp;
+    g.ordered = n_basic > 1 && g.want_ordered != 0;
+    g.n_depth = (g.ordered && current_mode() == PTK_MODE_MIS && g.spp == 1) ? g.traceDepth + 1 : 1;      // (samples per launch: one plane per sample)
+    if ((unsigned long long)g.n_depth * plane >= (1ull << 31)) g.n_depth = 1;       // (sample stride must fit 31 bits: then MIS merges the iteration's own sum)
+    const size_t n_planes = n_basic * g.n_depth;
     if ((rc = dalloc(&g.planes, plane * n_planes))) return rc;
     if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * n_planes)) != hipSuccess) return (int)e;
-    if (n_planes > 1) {
+    if (n_basic > 1) {
         if ((rc = dalloc(&g.image, plane))) return rc;
         if ((e = hipMemset(g.image, 0, sizeof(float) * plane)) != hipSuccess) return (int)e;
     } else g.image = g.planes;
-    g.ordered = n_planes > 1 && (g.want_ordered >= 0 ? g.want_ordered != 0 : current_mode() != PTK_MODE_MIS);
+    if (g.ordered) {
+        const size_t n_flags = n_planes * (((size_t)g.P + 63) / 64);
+        if ((rc = dalloc(&g.flags, n_flags))) return rc;
+        if ((e = hipMemset(g.flags, 0, n_flags)) != hipSuccess) return (int)e;
+    }
     g.last_merged = nullptr;
     if ((rc = dalloc(&g.ray_total, 1))) return rc;
     if ((e = hipMemset(g.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return (int)e;
@@ -359,8 +378,9 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
     ws.iter_stride = (g.tiles ? 1 : g.n_lanes) * g.n_shards;       // (tiles in flight: every lane renders every iteration)
     ws.dbg_shift0 = g_debug_slot_shift; ws.dbg_shift_deep = g_debug_slot_shift_deep;
     ws.gen_late = L.gen_late;
-    // ordered accumulation in BSDF / DIRECT: the lane's planes are zero when the launch starts and a pixel receives at most one add — a plain store
-    if (g.ordered && mode != PTK_MODE_MIS) ws.plane_stride |= PTK_FILM_STORE;
+    // ordered accumulation: the lane's planes are zero when the launch starts and a (pixel, plane) receives at most one add — a plain store (MIS
+    // without planes per bounce — the context was initialised in another mode — adds bounce by bounce into the one plane)
+    if (g.ordered && (g.n_depth > 1 || mode != PTK_MODE_MIS)) ws.plane_stride |= PTK_FILM_STORE;
     if (g.tiles) {
         const int li = (int)(&L - &g.lanes[0]);
         ws.cum_prev = li > 0 ? g.lanes[li - 1].cum : nullptr; ws.cum_out = L.cum; ws.cum_stride = g.traceDepth + 2; ws.ring_div = g.n_shards;
@@ -491,20 +511,22 @@ int replay_iteration(Lane& L, int iter, int mode) {
 static void reset_hints() { for (Lane& l : g.lanes) { l.full_bounces = g.traceDepth; l.gen_late = 0; l.counts_pending = false; l.fresh_hint = 0; } }
 
 // ORDERED ACCUMULATION (round 4).  With several planes (iterations in flight, samples per launch) a launch adds its radiance into the lane's own
-// planes, zero when it starts, and this merge — on the lane's stream, behind the launch — folds them into the image in ITERATION order: it waits
-// for the merge of the previous call (another lane's stream; one event edge, no host wait).  image = ((image + it_1) + it_2) + ...: the
-// reference's running sum (pathtrace.cu:600).  BSDF / DIRECT add at most once per pixel and iteration, so the image is bit-identical to one
-// iteration at a time; MIS adds bounce by bounce, the plane holds the iteration's own sum and only the float association differs
-// (ptk_kernels.hip: k_merge_planes).  The lane's next launch follows the merge on the same stream and finds its planes zero again.
-// (Measured and dropped: the merges on a stream of their own, so that no lane waits for another — a fourth stream beside three lanes shares a
-// hardware queue with one of them, cornell 21.9 -> 15.2 Grays/s.)  Cost: one launch per iteration that reads the whole plane — cornell BSDF -1.4 .. -3.3 %,
-// DIRECT -5 %, mis_test 1024^2 BSDF (a 42-us iteration) -12 % (profiles/r4_ab_ordered_accumulation.txt) — which is why MIS, where ordering cannot make the image bit-identical anyway, keeps accumulating
-// planes (ptk_set_ordered_accumulation: auto).
+// planes, zero when it starts — one per sample; one per BOUNCE when the context was initialised in MIS mode — so that every (pixel, plane) receives
+// at most one add: BSDF / DIRECT add once per pixel and iteration (pathtrace.cu:398,486 or the ENV add of :303-311), MIS once per pixel and bounce
+// (:556 or :572 or the ENV add).  This merge — on the lane's stream, behind the launch — folds them into the image in the reference's order of
+// adds, iteration by iteration, bounce by bounce: it waits for the merge of the previous call (another lane's stream; one event edge, no host
+// wait).  image = ((image + a_1) + a_2) + ...: the reference's running sum (pathtrace.cu:600), bit-identical to one iteration at a time in every
+// sample mode (ptk_kernels.hip: k_merge_planes; touched-tile flags keep the sparse adds of deep bounces cheap).  The lane's next launch follows
+// the merge on the same stream and finds its planes zero again.  Exceptions, both valid images with another float association: samples per launch
+// in MIS (one plane per sample holds the sample's own sum) and a context initialised in BSDF / DIRECT that is switched to MIS without
+// re-initialising.  Measured and dropped: the merges on a stream of their own, so that no lane waits for another — a fourth stream beside three
+// lanes shares a hardware queue with one of them, cornell 21.9 -> 15.2 Grays/s.  Cost against planes that accumulate
+// (ptk_set_ordered_accumulation(0); profiles/r4_ab_ordered_accumulation.txt): cornell BSDF -3 %, MIS -5 %, mis_test 1024^2 MIS -7 %, BSDF -10 %.
 static int merge_lane(Lane& L) {
     if (!g.ordered) return 0;                            // one plane (the launches add into the image itself), or planes that accumulate (resolve_image)
     hipError_t e;
     if (g.last_merged && g.last_merged != L.merged && (e = hipStreamWaitEvent(L.stream, g.last_merged, 0)) != hipSuccess) return (int)e;
-    const int rc = launch_merge_planes(g.image, L.plane, g.spp, 3 * (size_t)g.P, L.stream);
+    const int rc = launch_merge_planes(g.image, L.plane, L.flags, g.spp * g.n_depth, g.P, L.stream);
     if (rc) return rc;
     if ((e = hipEventRecord(L.merged, L.stream)) != hipSuccess) return (int)e;
     g.last_merged = L.merged;
@@ -632,10 +654,10 @@ int ptk_set_tiles_in_flight(int tiles) {
     g.want_tiles = tiles; g.sched_explicit = true;
     return 0;
 }
-/* Accumulation with several radiance planes (iterations in flight, samples per launch; set before ptk_pathtrace_init): 1 = ordered — every
- * launch's planes are folded into the image in call order (merge_lane: BSDF / DIRECT bit-identical to one iteration at a time); 0 = the planes
- * accumulate and are summed when the image is read, ((p0 + p1) + p2) + ...; -1 (default) = ordered unless the sample mode at
- * ptk_pathtrace_init is MIS, whose bounce-by-bounce adds no order can make bit-identical (so it skips the merges' cost). */
+/* Accumulation with several radiance planes (iterations in flight, samples per launch; set before ptk_pathtrace_init): -1 / 1 (default) = ordered —
+ * every launch's planes are folded into the image in the reference's order of adds (merge_lane: bit-identical to one iteration at a time);
+ * 0 = the planes accumulate and are summed when the image is read, ((p0 + p1) + p2) + ... (no merge launches: 3-10 % faster, float association
+ * differs). */
 int ptk_set_ordered_accumulation(int on) {
     if (on < -1 || on > 1 || g.live) return PTK_E_BADARG;
     g.want_ordered = on;
@@ -781,7 +803,8 @@ int ptk_debug_slot_shift(int k0, int k1) { g_debug_slot_shift = k0; g_debug_slot
 int ptk_debug_clear_image(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();
-    int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp)));
+    int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp * g.n_depth)));
+    if (!rc && g.flags) rc = rc_of(hipMemset(g.flags, 0, (size_t)g.n_lanes * g.spp * g.n_depth * (((size_t)g.P + 63) / 64)));
     if (!rc && g.image != g.planes) rc = rc_of(hipMemset(g.image, 0, sizeof(float) * 3 * (size_t)g.P));
     return rc ? rc : rc_of(hipDeviceSynchronize());      // null-stream clear vs the lanes' non-blocking streams
 }
@@ -873,19 +896,17 @@ int ptk_timer_stop(float* ms) {
 // ---------------------------------------------------------------- C++ API (pathtrace.h)
 void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
-// Schedule of the C++ API, chosen at pathtraceInit (the four reference signatures have no room for knobs).  DEFAULT: in BSDF / DIRECT mode three
-// iterations in flight + hipGraph replay with ordered accumulation — scene->state.image is bit-identical to one iteration at a time, i.e. to the
-// reference's running sum (merge_lane) — and one iteration at a time in MIS (whose bounce-by-bounce adds no overlap of whole iterations
-// reproduces; PTK_TILES=3 is the bit-identical overlap there).  The viewer re-initialises on a sample-mode change (main.cpp:173-201,
-// preview.cpp:247), so the choice follows the mode.  Overrides: PTK_IN_FLIGHT=<L>, PTK_TILES=<K>, PTK_GRAPH=0|1, PTK_ORDERED=-1|0|1 (as the
-// ptk_set_* calls, which a host may also make itself before pathtraceInit), PTK_EAGER_IMAGE=1 = refresh
+// Schedule of the C++ API, chosen at pathtraceInit (the four reference signatures have no room for knobs).  DEFAULT: three iterations in flight +
+// hipGraph replay with ordered accumulation — scene->state.image is bit-identical to one iteration at a time, i.e. to the reference's running sum,
+// in every sample mode (merge_lane; MIS gets one plane per bounce, which is decided by the mode at pathtraceInit: the viewer re-initialises on a
+// sample-mode change, main.cpp:173-201, preview.cpp:247).  Overrides: PTK_IN_FLIGHT=<L> (1 = the reference's own schedule), PTK_TILES=<K>,
+// PTK_GRAPH=0|1, PTK_ORDERED=-1|0|1 (as the ptk_set_* calls, which a host may also make itself before pathtraceInit), PTK_EAGER_IMAGE=1 = refresh
 // scene->state.image after EVERY call like pathtrace.cu:809-810 (a 7.7 MB D2H and a host wait per 0.3 ms iteration at 800 x 800).
 void pathtraceInit(Scene* scene) {
     if (!g.live) {
         const bool env_sched = getenv("PTK_IN_FLIGHT") || getenv("PTK_TILES") || getenv("PTK_GRAPH");
         if (!g.sched_explicit && !env_sched) {
-            const bool overlap = current_mode() != PTK_MODE_MIS;
-            g.n_lanes = overlap ? 3 : 1; g.use_graph = overlap; g.want_tiles = 1;
+            g.n_lanes = 3; g.use_graph = true; g.want_tiles = 1;
         }
         if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.n_lanes = l; }
         if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;

@@ -41,6 +41,12 @@ inline SceneView dev_view(const ::Scene& s) {
     return d;
 }
 
+// The radiance planes a launch adds into (ptk_kernels.hip: film_add).  Layout float[sample][depth][3 P]: one plane per sample of the launch
+// (plane_stride = floats per sample, 0 with one sample: pixelIndex then carries no sample bits; bit 31 = PTK_FILM_STORE) and — ordered accumulation
+// in MIS mode (pathtrace.hip: merge_lane) — one per bounce (depth_stride = 3 P, else 0).  flags (null = off): one byte per plane and 64 pixels,
+// set by every add (flag_sample_stride / flag_depth_stride = bytes per sample / per bounce), so that the merge visits touched tiles only.
+struct FilmArgs { float* img; unsigned char* flags; unsigned plane_stride, depth_stride, flag_sample_stride, flag_depth_stride; };
+
 // pipeline-internal launchers (ptk_kernels.hip); all asynchronous on `st`
 struct Workspace {               // per-render-context scratch, device memory
     int* agg_a = nullptr;        // per-block hit counts of the intersect stage
@@ -54,7 +60,9 @@ struct Workspace {               // per-render-context scratch, device memory
     int* list = nullptr;         // the work list [capacity]
     int* iter_dev = nullptr;     // device-resident iteration number (hipGraph replay); null = use the launch argument
     int iter_stride = 0;         // added to *iter_dev by the last kernel of an iteration
-    unsigned plane_stride = 0;   // floats per radiance plane (3*P); bit 31 = PTK_FILM_STORE (ptk_kernels.hip: pixel_ptr)
+    unsigned plane_stride = 0;   // floats per sample of the radiance planes (FilmArgs); bit 31 = PTK_FILM_STORE
+    unsigned depth_stride = 0;   // floats per bounce plane, 0 = one plane for all bounces
+    unsigned char* film_flags = nullptr; unsigned flag_sample_stride = 0, flag_depth_stride = 0;      // touched-tile flags of the planes (FilmArgs), null = off
     int spp = 1;                 // samples (iterations) per launch
     int slot_bias = 0;           // added to the compacted slot in the shading RNG key: part * W * H * spp under the tile partition, so
                                  // that two ranks never share a random stream (0 on one GPU = the reference's key)
@@ -92,7 +100,8 @@ int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& c
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool));
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);      // out = ((p0 + p1) + p2) + ...
-int launch_merge_planes(float* image, float* planes, int n_planes, size_t plane_len, hipStream_t st);      // image += planes in order; planes = 0
+int launch_merge_planes(float* image, float* planes, unsigned char* flags, int n_planes, int n_pixels, hipStream_t st);      // image += the touched tiles of planes[0], planes[1], ... in order; planes = 0, flags = 0
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);
+inline FilmArgs film_of(float* img, const Workspace& ws) { return FilmArgs{img, ws.film_flags, ws.plane_stride, ws.depth_stride, ws.flag_sample_stride, ws.flag_depth_stride}; }
 
 } // namespace ptk

@@ -125,20 +125,22 @@ __device__ __forceinline__ int prefix_block(int nw, const int* __restrict__ agg,
     return total;
 }
 
-// pixelIndex -> its three floats in the radiance planes.  With samples per launch (spp > 1) bits 24..30 of pixelIndex carry the sample's
-// plane; a launch with spp == 1 passes plane_stride = 0 and all 31 bits are the pixel (frames of 2^24 pixels and more).  Wave-uniform selects.
-// Bit 31 of plane_stride (PTK_FILM_STORE; 3 P < 2^31, pathtrace.hip: context_init): the launch adds into a plane that is zero when the iteration starts
-// and receives at most ONE add per pixel (ordered accumulation in BSDF / DIRECT mode) — the add is a plain store, no dependent load.
-__device__ __forceinline__ float* pixel_ptr(float* img, unsigned plane_stride, int pix) {
-    const unsigned stride = plane_stride & ~PTK_FILM_STORE;
+// pixelIndex -> its three floats in the radiance planes (FilmArgs, ptk_internal.h).  With samples per launch (spp > 1) bits 24..30 of pixelIndex carry
+// the sample's plane; a launch with spp == 1 passes plane_stride = 0 and all 31 bits are the pixel (frames of 2^24 pixels and more).  With planes per
+// depth (ordered accumulation in MIS, pathtrace.hip: merge_lane) the add of bounce `depth` goes to that bounce's plane.  Wave-uniform selects.
+// Bit 31 of plane_stride (PTK_FILM_STORE; 3 P < 2^31, pathtrace.hip: context_init): the plane is zero when the iteration starts and receives at most ONE
+// add per pixel — the add is a plain store, no dependent load.  flags (may be null): one byte per 64 pixels and plane, set by every add, so that the
+// merge visits touched tiles only.
+__device__ __forceinline__ void film_add(const FilmArgs& f, int depth, int pix, f3 c) {
+    const unsigned stride = f.plane_stride & ~PTK_FILM_STORE;
     const unsigned mask = stride ? 0xFFFFFFu : 0x7FFFFFFFu;
     const unsigned plane = stride ? ((unsigned)pix >> 24) : 0u;
-    return img + (size_t)plane * stride + 3 * (size_t)((unsigned)pix & mask);
-}
-__device__ __forceinline__ void film_add(float* img, unsigned plane_stride, int pix, f3 c) {
-    // one live path per (sample plane, pixel): plain read-modify-write, no atomics.  plane = pix >> 24 (0 unless spp > 1)
-    float* p = pixel_ptr(img, plane_stride, pix);
-    if (plane_stride & PTK_FILM_STORE) { p[0] = c.x; p[1] = c.y; p[2] = c.z; }      // wave-uniform
+    const unsigned px = (unsigned)pix & mask;
+    const unsigned d = f.depth_stride ? (unsigned)depth : 0u;
+    float* p = f.img + (size_t)plane * stride + (size_t)d * f.depth_stride + 3 * (size_t)px;
+    if (f.flags) f.flags[(size_t)plane * f.flag_sample_stride + (size_t)d * f.flag_depth_stride + (px >> 6)] = 1;      // wave-uniform branch
+    // one live path per (sample plane, pixel): plain read-modify-write, no atomics
+    if (f.plane_stride & PTK_FILM_STORE) { p[0] = c.x; p[1] = c.y; p[2] = c.z; }      // wave-uniform
     else { p[0] += c.x; p[1] += c.y; p[2] += c.z; }
 }
 __device__ __forceinline__ float4 ld4(const float* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
@@ -884,19 +886,19 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_finalize2(SceneView S, int n_arg,
 }
 // environment map on a miss, fused pipeline: slot g of the traced stream missed iff the top bits of hr[g] are 10 (00: hit, 11: empty slot)
 __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss2(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths, const int* __restrict__ hr,
-                                                          float* __restrict__ img, unsigned plane_stride) {
+                                                          FilmArgs film, int depth) {
     const int n = d_n ? *d_n : n_arg;
     const int g = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (blockIdx.x * PTK_BLOCK >= n || ((unsigned)hr[g] >> 30) != 2u) return;      // status bits 10 = a traced ray that missed
     const float4 d4 = ld4(paths.d_bnc, g), c4 = ld4(paths.col_pdf, g);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)g + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
-    film_add(img, plane_stride, pix, c);
+    film_add(film, depth, pix, c);
 }
 
 // environment map on a miss (pathtrace.cu:303-311): img[pixel] += processNAN(color * env(sphere2Plane(direction)))
 __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, const int* __restrict__ d_n, PtkPaths paths,
-                                                         const int* __restrict__ valid, float* __restrict__ img, unsigned plane_stride,
+                                                         const int* __restrict__ valid, FilmArgs film, int depth,
                                                          const int* __restrict__ srcidx) {
     const int n = d_n ? *d_n : n_arg;
     const int g = blockIdx.x * PTK_BLOCK + threadIdx.x;
@@ -905,7 +907,7 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, 
     const float4 d4 = ld4(paths.d_bnc, i), c4 = ld4(paths.col_pdf, i);
     const int pix = __float_as_int(paths.o_pix[4 * (size_t)i + 3]);
     const f3 c = nan_to_zero(mk3(c4.x, c4.y, c4.z) * env_radiance(S, mk3(d4.x, d4.y, d4.z)));
-    film_add(img, plane_stride, pix, c);
+    film_add(film, depth, pix, c);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -914,9 +916,9 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_env_miss(SceneView S, int n_arg, 
 // ------------------------------------------------------------------------------------------------------------------
 struct PathRegs { f3 o, d, col; int pix, bounces; float prevPdf; };
 
-struct Film { float* img; unsigned plane_stride; };       // radiance planes: float[plane][3*P]
+struct Film { FilmArgs a; int depth; };       // the radiance planes and the bounce whose adds this launch makes
 __device__ __forceinline__ void add_radiance(const Film& film, int pix, f3 c) {
-    film_add(film.img, film.plane_stride, pix, c);
+    film_add(film.a, film.depth, pix, c);
 }
 
 // Material records staged in LDS by the shading kernel (first PTK_LDS_MATS materials; the rest, if any, come from global memory):
@@ -1018,7 +1020,7 @@ template <int MODE>
 __global__ void __launch_bounds__(PTK_BLOCK) k_shade(SceneView S, int iter_arg, int depth, int n_arg, const int* __restrict__ d_n,
                                                       PtkHits hits, PtkPaths paths, int* __restrict__ valid_b, float* __restrict__ img_base) {
     const int n = d_n ? *d_n : n_arg;
-    const Film img = {img_base, 0u};
+    const Film img = {FilmArgs{img_base, nullptr, 0u, 0u, 0u, 0u}, 0};
     const int b = blockIdx.x;
     if (b * PTK_BLOCK >= n) return;
     GeomStage gs; gs.xf = nullptr; gs.on = false;
@@ -1145,7 +1147,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
                                                       const int* __restrict__ d_n, PtkHits hits, PtkPaths paths,
                                                       const int* __restrict__ valid_a, const int* __restrict__ agg_a,
                                                       int* __restrict__ agg_b,
-                                                      float* __restrict__ img_base, unsigned plane_stride, int spp, int slot_bias,
+                                                      FilmArgs film, int spp, int slot_bias,
                                                       const int* __restrict__ srcidx, PtkPaths seg_out, SegTail seg_tail) {
     // srcidx  : physical slot of every dense path (segmented input stream), nullptr = the stream is dense
     // seg_out : block-local compaction: survivors go to seg_out[b * NT + rank within the block] and agg_b[b] is their number
@@ -1157,7 +1159,7 @@ __global__ void __launch_bounds__(NT, 4) k_shade_binned(SceneView S, int iter_ar
     __shared__ int s_red[NW];
     const int n = d_n ? *d_n : n_arg;
     const int iter = ((iter_ptr ? *iter_ptr : iter_arg) - 1) * spp + 1;
-    const Film img = {img_base, plane_stride};
+    const Film img = {film, depth};
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (b * NT >= n) {
         // no live path at all: nobody runs the tail, block 0 does the (empty) bookkeeping of the bounce
@@ -1434,7 +1436,7 @@ template <int MODE, bool GEN, bool SPLIT, bool COMPACT>
 #define PTK_FUSED_WAVES_GEN 0     // > 0: occupancy the camera launches are compiled for; 0: that of their mode (measured: MIS layout 22.2 at six vs 21.1 Grays/s at seven on mis_test)
 #endif
 __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ? PTK_FUSED_WAVES_GEN : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF)))) k_shade_trace(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg,
-                                                             const int* __restrict__ d_n, TraceIO io, float* __restrict__ img_base, unsigned plane_stride,
+                                                             const int* __restrict__ d_n, TraceIO io, FilmArgs film,
                                                              int spp, int slot_bias, SegTail2 tail) {
     constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6;
     // Occupancy: 22.1 KB of LDS and <= 72 VGPRs = seven blocks per CU (with the 16-primitive pair list and 64 staged materials of the
@@ -1465,7 +1467,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
 
     const int step = iter_ptr ? *iter_ptr : iter_arg;
     const int n = GEN ? gen.n_pix * spp : (d_n ? *d_n : n_arg);      // paths of the bounce being shaded (GEN: rays to generate)
-    const Film img = {img_base, plane_stride};
+    const Film img = {film, depth};               // (depth = the bounce being shaded; -1 in the camera launch, which shades nothing)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if ((int)blockIdx.x * NT >= n) {
         // no live path at all: nobody runs the tail, block 0 does the (empty) bookkeeping of the bounce
@@ -1861,7 +1863,7 @@ struct TailArgs {
     const int* nshaded;                      // paths the last full-width launch shaded (its windows = ceil / 256): counts[depth0 - 1], or hcounts[depth0 - 1] after a hit-dense launch
     PtkPaths cur, nxt;                       // cur: the stream entering bounce depth0 (windowed if G.pref != null)
     Gather G;
-    float* img; unsigned plane_stride; int spp, slot_bias;
+    FilmArgs film; int spp, slot_bias;
     int dbg_shift0, dbg_shift_deep;          // test hooks only (0 in the product): extra key offset at depth 0 / depth >= 1
     unsigned long long* ray_total;
     int* iter_advance; int iter_stride;
@@ -1883,12 +1885,12 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
     const MatTable mt = stage_materials<NT>(S, s_mats);
     const int step = A.iter_ptr ? *A.iter_ptr : A.iter_arg;
     const int iter = (step - 1) * A.spp + 1;
-    const Film img = {A.img, A.plane_stride};
     PtkPaths cur = A.cur, nxt = A.nxt;
     Gather G = A.G;
     int n = A.hit_dense ? *A.nhits : A.counts[A.depth0];        // paths to look at in the first bounce: its hits (hit-dense) or its live paths
     const int crow = cum_row(step, A.ring_div, A.cum_stride);
     for (int depth = A.depth0; depth < A.trace_depth; ++depth) {
+        const Film img = {A.film, depth};
         if (n <= 0) {                                            // nothing left: the remaining bounces are empty
             for (int d = depth + 1 + threadIdx.x; d <= A.trace_depth; d += NT) A.counts[d] = 0;
             if (A.cum_out) for (int d = depth + threadIdx.x; d <= A.trace_depth; d += NT) if (!(A.have_hits && d == A.depth0)) A.cum_out[crow + d] = cum_read(A.cum_prev, crow, d);
@@ -2011,38 +2013,42 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_sum_planes(const float* __restric
     out[i] = s;
 }
 
-// ORDERED ACCUMULATION (round 4; pathtrace.hip: merge_lane).  With several iterations in flight (or several samples per launch) an iteration
-// adds its radiance into a plane of its own, zero when it starts; this kernel then folds the launch's planes into the image IN ITERATION ORDER and
-// leaves them zero for the lane's next launch: image = ((image + it_1) + it_2) + ... — the reference's running sum (pathtrace.cu:600).  In BSDF and
-// DIRECT mode a pixel receives at most one add per iteration, its plane value IS that add and image + 0 == image: the image is bit-identical to
-// one iteration at a time.  (MIS adds next-event terms bounce by bounce; there the plane holds the iteration's own sum and the result differs from
-// the reference's in float association only.)  Elements whose planes are all zero are neither read from nor written to the image.
-template <typename V>
-__global__ void __launch_bounds__(PTK_BLOCK) k_merge_planes(float* __restrict__ image, float* __restrict__ planes, int n_planes, size_t plane_len) {
-    constexpr int N = sizeof(V) / sizeof(float);
-    const size_t i = ((size_t)blockIdx.x * PTK_BLOCK + threadIdx.x) * N;
-    if (i >= plane_len) return;
-    V v;
+// ORDERED ACCUMULATION (round 4; pathtrace.hip: merge_lane).  With several iterations in flight (or several samples per launch) an iteration adds
+// its radiance into planes of its own, zero when it starts — one per sample and, in MIS mode, per bounce — and every (pixel, plane) receives at most
+// ONE add: BSDF / DIRECT add once per pixel and iteration (pathtrace.cu:398,486 or the ENV add of :303-311); MIS adds once per pixel and BOUNCE
+// (the next-event term of :572, the light hit of :556 or the ENV add, whichever ends or continues the path there).  This kernel folds the planes
+// into the image in the order the reference made those adds — sample by sample, bounce by bounce — and leaves them zero for the lane's next launch:
+// image = ((image + a_1) + a_2) + ..., the reference's running sum (pathtrace.cu:600), bit for bit in every sample mode.  A wave owns a tile of 64
+// pixels; it visits the planes whose touched-tile flag is set (film_add), so the sparse adds of deep bounces and open scenes cost nothing elsewhere.
+__global__ void __launch_bounds__(PTK_BLOCK) k_merge_planes(float* __restrict__ image, float* __restrict__ planes, unsigned char* __restrict__ flags,
+                                                            int n_planes, int n_pixels, int n_tiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (PTK_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int px = tile * 64 + lane;
+    const bool in = px < n_pixels;
+    const size_t plane_len = 3 * (size_t)n_pixels;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
     bool have = false;
-    for (int p = 0; p < n_planes; ++p) {
-        V* src = reinterpret_cast<V*>(planes + (size_t)p * plane_len + i);
-        const V a = *src;
-        const float* af = reinterpret_cast<const float*>(&a);
-        bool nz = false;
-#pragma unroll
-        for (int k = 0; k < N; ++k) nz |= af[k] != 0.0f;
-        if (!nz) continue;
-        if (!have) { v = *reinterpret_cast<const V*>(image + i); have = true; }
-        float* vf = reinterpret_cast<float*>(&v);
-#pragma unroll
-        for (int k = 0; k < N; ++k) vf[k] += af[k];
-        V z;
-        float* zf = reinterpret_cast<float*>(&z);
-#pragma unroll
-        for (int k = 0; k < N; ++k) zf[k] = 0.0f;
-        *src = z;
+    for (int q0 = 0; q0 < n_planes; q0 += 64) {
+        const int q = q0 + lane;
+        unsigned char* fp = flags + (size_t)(q < n_planes ? q : 0) * n_tiles + tile;
+        const bool dirty = q < n_planes && *fp != 0;
+        if (dirty) *fp = 0;
+        unsigned long long m = __ballot(dirty);
+        while (m) {                                              // wave-uniform: the touched planes of this tile, in order
+            const int k = __builtin_ctzll(m);
+            m &= m - 1ull;
+            float* p = planes + (size_t)(q0 + k) * plane_len + 3 * (size_t)px;
+            if (in) {
+                if (!have) { v0 = image[3 * (size_t)px]; v1 = image[3 * (size_t)px + 1]; v2 = image[3 * (size_t)px + 2]; }
+                v0 += p[0]; v1 += p[1]; v2 += p[2];
+                p[0] = 0.f; p[1] = 0.f; p[2] = 0.f;
+            }
+            have = true;
+        }
     }
-    if (have) *reinterpret_cast<V*>(image + i) = v;
+    if (have && in) { image[3 * (size_t)px] = v0; image[3 * (size_t)px + 1] = v1; image[3 * (size_t)px + 2] = v2; }
 }
 
 #ifdef PTK_TEST_HOOKS
@@ -2146,16 +2152,16 @@ DevCamera to_dev_camera(const PtkCamera& c) {
 }
 
 int launch_shade_binned(int mode, const SceneView& S, int iter, const int* iter_ptr, int depth, int n, const int* d_n, PtkHits hits, PtkPaths paths,
-                        const int* va, const int* aa, int* ab, float* img, unsigned plane_stride, int spp, int slot_bias, hipStream_t st,
+                        const int* va, const int* aa, int* ab, const FilmArgs& film, int spp, int slot_bias, hipStream_t st,
                         const int* srcidx, PtkPaths seg_out, SegTail seg_tail) {
     constexpr int NT = PTK_BLOCK;
     const int g = (n + NT - 1) / NT;
     if (g == 0) return 0;
     if (!seg_out.o_pix) return PTK_E_BADARG;
     switch (mode) {
-    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
-    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
-    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, img, plane_stride, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_BSDF: k_shade_binned<PTK_MODE_BSDF, NT><<<g, NT, 0, st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, film, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_DIRECTLI: k_shade_binned<PTK_MODE_DIRECTLI, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, film, spp, slot_bias, srcidx, seg_out, seg_tail); break;
+    case PTK_MODE_MIS: k_shade_binned<PTK_MODE_MIS, NT><<<g, NT, stage_bytes(S), st>>>(S, iter, iter_ptr, depth, n, d_n, hits, paths, va, aa, ab, film, spp, slot_bias, srcidx, seg_out, seg_tail); break;
     default: return PTK_E_BADARG;
     }
     return launch_rc();
@@ -2255,13 +2261,13 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
                                     ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr);
     if (rc) return rc;
     if (S.env_tex >= 0) {
-        k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, img, ws.plane_stride, G.src);
+        k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, film_of(img, ws), depth, G.src);
         if ((rc = launch_rc())) return rc;
     }
     mark(2, true);
     const bool fold = ws.seg_done != nullptr;                // the shading kernel's last block does the window bookkeeping itself
     const SegTail tail = {fold ? ws.seg_done : nullptr, ws.seg_pref, ws.seg_first, ws.counts + depth + 1, last_bounce ? ws.iter_dev : nullptr, ws.iter_stride};
-    rc = launch_shade_binned(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.agg_b, img, ws.plane_stride, ws.spp,
+    rc = launch_shade_binned(mode, S, iter, ws.iter_dev, depth, capacity, d_n, hits, cur, ws.valid_a, ws.agg_a, ws.agg_b, film_of(img, ws), ws.spp,
                              ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0), st, G.src, nxt, tail);
     mark(2, false);
     if (rc || fold) return rc;
@@ -2279,11 +2285,11 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
 // bounce dt into `nxt`.  Scenes with triangles continue with the work-list BVH stage on the survivors' physical slots.
 template <int MODE, bool GEN>
 static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
-                                const TraceIO& io, float* img, unsigned plane_stride, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
+                                const TraceIO& io, const FilmArgs& film, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
     const int g = grid_for(capacity);
-    if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
-    else if (compact) k_shade_trace<MODE, GEN, false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
-    else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, img, plane_stride, spp, slot_bias, tail);
+    if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
+    else if (compact) k_shade_trace<MODE, GEN, false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
+    else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
     return launch_rc();
 }
 // the fused pipeline's compact stream layout (k_shade_trace): no triangles, no textures, no MIS
@@ -2323,14 +2329,14 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     int rc;
     if (gen) {
         switch (mode) {                 // (the mode only matters for the hit-record layout the next launch expects: same kernel body)
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;   // (the MIS layouts carry the origin)
-        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;   // (the MIS layouts carry the origin)
+        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
         }
     } else {
         switch (mode) {
-        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
-        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, img, ws.plane_stride, ws.spp, sbias, tail, st); break;
+        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
+        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
         default: rc = PTK_E_BADARG;
         }
     }
@@ -2353,7 +2359,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
         if ((rc = launch_rc())) return rc;
     }
     if (S.env_tex >= 0) {
-        k_env_miss2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.paths, nxt.hr, img, ws.plane_stride);
+        k_env_miss2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.paths, nxt.hr, film_of(img, ws), dt);
         if ((rc = launch_rc())) return rc;
     }
     return 0;
@@ -2377,7 +2383,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     A.cum_prev = ws.cum_prev; A.cum_out = ws.cum_out; A.cum_stride = ws.cum_stride; A.ring_div = ws.ring_div;
     const bool seg = ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};
-    A.img = img; A.plane_stride = ws.plane_stride; A.spp = ws.spp; A.slot_bias = ws.slot_bias; A.dbg_shift0 = ws.dbg_shift0; A.dbg_shift_deep = ws.dbg_shift_deep;
+    A.film = film_of(img, ws); A.spp = ws.spp; A.slot_bias = ws.slot_bias; A.dbg_shift0 = ws.dbg_shift0; A.dbg_shift_deep = ws.dbg_shift_deep;
     A.ray_total = ws.ray_total; A.iter_advance = ws.iter_dev; A.iter_stride = ws.iter_stride;
     switch (mode) {
     case PTK_MODE_BSDF: k_tail<PTK_MODE_BSDF><<<1, PTK_TAIL_BLOCK, stage_bytes(S), st>>>(S, A); break;
@@ -2395,14 +2401,10 @@ int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float
     k_sum_planes<<<g, PTK_BLOCK, 0, st>>>(planes, n_planes, plane_len, out);
     return launch_rc();
 }
-int launch_merge_planes(float* image, float* planes, int n_planes, size_t plane_len, hipStream_t st) {
-    if (plane_len % 4 == 0) {                      // every plane then starts on a 16-byte boundary
-        const int g = (int)((plane_len / 4 + PTK_BLOCK - 1) / PTK_BLOCK);
-        k_merge_planes<float4><<<g, PTK_BLOCK, 0, st>>>(image, planes, n_planes, plane_len);
-    } else {
-        const int g = (int)((plane_len + PTK_BLOCK - 1) / PTK_BLOCK);
-        k_merge_planes<float><<<g, PTK_BLOCK, 0, st>>>(image, planes, n_planes, plane_len);
-    }
+int launch_merge_planes(float* image, float* planes, unsigned char* flags, int n_planes, int n_pixels, hipStream_t st) {
+    const int n_tiles = (n_pixels + 63) / 64;
+    const int g = (n_tiles + PTK_BLOCK / 64 - 1) / (PTK_BLOCK / 64);
+    k_merge_planes<<<g, PTK_BLOCK, 0, st>>>(image, planes, flags, n_planes, n_pixels, n_tiles);
     return launch_rc();
 }
 
@@ -2448,7 +2450,7 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
                                     g_abi_hflag, g_abi_hagg, false, (hipStream_t)stream, [](int, bool) {}, Gather{nullptr, nullptr, nullptr}, PTK_WALK_WIDE, 4);
     if (rc || !img || S.env_tex < 0) return rc;
     if (!paths.col_pdf) return PTK_E_BADARG;
-    k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, img, 0u, nullptr);
+    k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, FilmArgs{img, nullptr, 0u, 0u, 0u, 0u}, 0, nullptr);
     return launch_rc();
 }
 

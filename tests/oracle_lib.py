@@ -171,24 +171,29 @@ class Scene:
 class Accumulator:
     """The product's accumulation, restated for the checks (csrc/pathtrace.hip: merge_lane / resolve_image; include/ptk.h:
     ptk_set_ordered_accumulation).  ONE radiance plane (one iteration at a time, one sample per launch; tiles in flight): every add goes into the
-    image itself, as in the reference (pathtrace.cu:556,572,600).  SEVERAL planes (L iterations in flight and / or S samples per launch):
-      ordered  — a launch adds into planes of its own, zero when it starts, which are folded into the image in call order when it is done:
-                 image = ((image + it_1) + it_2) + ...; BSDF / DIRECT add at most once per pixel and iteration, so this IS the plain running sum;
-      otherwise — lane l's planes accumulate its calls l+1, l+1+L, ... and the image is ((plane_0 + plane_1) + plane_2) + ... over lanes x samples.
-    ordered=None follows the product's default: ordered unless the sample mode at init is MIS."""
+    image itself, as in the reference (pathtrace.cu:398,486,556,572,600).  SEVERAL planes (L iterations in flight and / or S samples per launch):
+      ordered (default) — a launch adds into planes of its own (one per sample; one per bounce when the context was initialised in MIS
+                 mode with one sample per launch), zero when it starts, every (pixel, plane) receiving one add, and the planes are folded into the image in the reference's
+                 order of adds when the launch is done: the image IS the plain running sum, whatever the mode.  (A context initialised in BSDF /
+                 DIRECT that is switched to MIS later has one plane per sample: MIS iterations then add their own sum.)
+      ordered=False — lane l's planes accumulate its calls l+1, l+1+L, ... and the image is ((plane_0 + plane_1) + plane_2) + ... over lanes x samples."""
 
-    def __init__(self, P, lanes=1, spp=1, mode=0, ordered=None):
+    def __init__(self, P, lanes=1, spp=1, mode=0, ordered=True):
         self.lanes, self.spp = lanes, spp
         self.single = lanes * spp <= 1
-        self.ordered = (mode != MODE_MIS) if ordered is None else bool(ordered)
+        self.ordered = bool(ordered)
+        self.per_bounce = mode == MODE_MIS and spp == 1      # planes per bounce: fixed at ptk_pathtrace_init by the sample mode of that moment
         self.image = np.zeros((P, 3), np.float32)
         self.planes = None if (self.single or self.ordered) else np.zeros((lanes, spp, P, 3), np.float32)
+
+    def _direct(self, mode):
+        return self.single or (self.ordered and (self.per_bounce or mode != MODE_MIS))
 
     def iteration(self, scene, mode, it, partition=(1, 0, 1), step=None):
         """one call of ptk_pathtrace(.., step) with one sample per launch; it = the iteration it renders (== step unless iterations are sharded)"""
         assert self.spp == 1
         step = it if step is None else step
-        if self.single:
+        if self._direct(mode):
             return scene.pathtrace(mode, it, self.image, partition=partition)
         if self.ordered:
             tmp = np.zeros_like(self.image)
@@ -198,8 +203,9 @@ class Accumulator:
         return scene.pathtrace(mode, it, self.planes[(step - 1) % self.lanes][0], partition=partition)
 
     def batch(self, scene, mode, step, partition=(1, 0, 1)):
-        """one call of ptk_pathtrace(.., step) with spp samples per launch"""
-        if self.single:
+        """one call of ptk_pathtrace(.., step) with spp samples per launch (planes per bounce are a one-sample-per-launch feature: with spp > 1
+        every sample has one plane, folded into the image in sample order)"""
+        if self.spp == 1 and self._direct(mode):
             return scene.pathtrace_batch(mode, step, 1, self.image.reshape(1, -1, 3), partition=partition)
         if self.ordered:
             tmp = np.zeros((self.spp,) + self.image.shape, np.float32)

@@ -384,14 +384,13 @@ def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
     assert png.shape == (48, 64, 3) and np.array_equal(png, pix)
 
 
-@pytest.mark.parametrize("mode,flags,lanes", [("mis", (), 1), ("mis", ("--eager",), 1), ("mis", ("--in-flight", "3", "--graph", "1"), 3),
+@pytest.mark.parametrize("mode,flags,lanes", [("mis", (), 3), ("mis", ("--eager",), 3), ("mis", ("--in-flight", "1", "--graph", "0"), 1),
                                               ("bsdf", (), 3), ("bsdf", ("--in-flight", "1", "--graph", "0"), 1), ("direct", (), 3)])
 def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, mode, flags, lanes):
     """The C++ pathtrace() only enqueues (no D2H, no host wait, SURVEY 8b "Outputs"); pathtraceResolve() makes scene->state.image and
-    TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle, bit for bit — MIS at the defaults (one iteration at a
-    time: the reference's order), with a resolve after every call (--eager = pathtrace.cu:809-810) and with three iterations in flight + graph
-    replay (the lanes' planes summed in order); BSDF / DIRECT at the defaults (three iterations in flight + graph replay, ordered accumulation)
-    == the oracle's PLAIN SEQUENTIAL render == the explicit one-at-a-time schedule."""
+    TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle's PLAIN SEQUENTIAL render, bit for bit, in every sample
+    mode — at the API's defaults (three iterations in flight + graph replay, ordered accumulation), with a resolve after every call
+    (--eager = pathtrace.cu:809-810) and in the explicit one-at-a-time schedule."""
     import subprocess
     exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
     base = str(tmp_path / "lazy")
@@ -405,15 +404,9 @@ def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, mode, flags, lanes):
     img = np.fromfile(base + ".6samp.f32", np.float32).reshape(-1, 3)
     o = orc.Scene(os.path.join(SC, scene), res=(W, H), depth=D)
     m = {"mis": orc.MODE_MIS, "bsdf": orc.MODE_BSDF, "direct": orc.MODE_DIRECTLI}[mode]
-    if mode == "mis":
-        acc = orc.Accumulator(o.P, lanes, 1, m)
-        for it in range(1, 7):
-            acc.iteration(o, m, it)
-        ref = acc.img
-    else:
-        ref = np.zeros((o.P, 3), np.float32)
-        for it in range(1, 7):
-            o.pathtrace(m, it, ref)
+    ref = np.zeros((o.P, 3), np.float32)
+    for it in range(1, 7):
+        o.pathtrace(m, it, ref)
     assert ref.sum() > 0
     assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
 
@@ -633,12 +626,16 @@ def test_iterations_in_flight(ptk, orc, torch_cuda, name, res, depth, mode, lane
 
 
 @pytest.mark.parametrize("name,res,depth,mode", [("cornell.txt", (200, 160), 8, "BSDF"), ("mis_test.txt", (200, 160), 8, "DIRECT"), ("bunny_cornell.txt", (96, 96), 6, "BSDF"),
-                                                 ("mis_test.txt", (160, 160), 10, "BSDF"), ("textureEnv_test.txt", (128, 128), 6, "BSDF")])
+                                                 ("mis_test.txt", (160, 160), 10, "BSDF"), ("textureEnv_test.txt", (128, 128), 6, "BSDF"),
+                                                 ("cornell.txt", (200, 160), 8, "MIS"), ("mis_test.txt", (160, 160), 12, "MIS"), ("bunny_cornell.txt", (96, 96), 6, "MIS"),
+                                                 ("textureEnv_test.txt", (128, 128), 6, "MIS"), ("metallic_analytic.txt", (131, 77), 7, "MIS")])
 def test_iterations_in_flight_keep_the_reference_order(ptk, orc, torch_cuda, name, res, depth, mode):
     """ORDERED ACCUMULATION (round 4).  In BSDF and DIRECT mode a pixel receives at most one add per iteration (pathtrace.cu:398,486 and the
-    ENV add of :303-311), so with every launch's plane folded into the image in iteration order the image of THREE ITERATIONS IN FLIGHT +
+    ENV add of :303-311), in MIS at most one per BOUNCE (:556 or :572 or the ENV add); an iteration in flight adds into planes of its own —
+    one per bounce in MIS — and they are folded into the image in the reference's order of adds.  So the image of THREE ITERATIONS IN FLIGHT +
     graph replay — the configuration bench.py's headline is timed in — is the reference's own running sum (pathtrace.cu:600): bit-identical to
-    one iteration at a time and to the oracle's plain sequential render, eleven iterations (incl. the k_tail regime and the ENV adds)."""
+    one iteration at a time and to the oracle's plain sequential render, eleven iterations (incl. the k_tail regime, the ENV adds, a frame
+    whose pixel count is no multiple of 64)."""
     m = MODES[mode]
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
@@ -657,16 +654,16 @@ def test_iterations_in_flight_keep_the_reference_order(ptk, orc, torch_cuda, nam
     assert np.array_equal(imgs[3], seq), int((imgs[3] != seq).any(axis=1).sum())
 
 
-@pytest.mark.parametrize("mode,ordered", [("MIS", 1), ("BSDF", 0), ("MIS", 0)])
+@pytest.mark.parametrize("mode,ordered", [("MIS", 1), ("BSDF", 0), ("MIS", 0), ("DIRECT", -1)])
 def test_accumulation_policy_can_be_forced(ptk, orc, torch_cuda, mode, ordered):
-    """ptk_set_ordered_accumulation(1 / 0) against the default (ordered unless MIS): MIS with every iteration's plane folded in order, BSDF with
-    planes that accumulate — three iterations in flight + graph replay, eight iterations == the oracle's restatement of that policy."""
-    name, res, depth, lanes = "cornell.txt", (128, 96), 6, 3
+    """ptk_set_ordered_accumulation(-1 / 1 = ordered, the default; 0 = planes that accumulate) — three iterations in flight + graph replay,
+    eight iterations == the oracle's restatement of that policy."""
+    name, res, depth, lanes = ("cornell.txt" if mode != "DIRECT" else "mis_test.txt"), (128, 96), 6, 3
     m = MODES[mode]
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     r = ptk.Renderer(s, m, in_flight=lanes, graph=True, ordered=ordered)
-    acc = orc.Accumulator(o.P, lanes, 1, m, ordered=bool(ordered))
+    acc = orc.Accumulator(o.P, lanes, 1, m, ordered=ordered != 0)
     for it in range(1, 9):
         r.iterate(it); acc.iteration(o, m, it)
     img = r.image(); r.close()
