@@ -3,7 +3,8 @@ import glob, os, shutil, sys
 RD = sys.argv[1] if len(sys.argv) > 1 else "r4"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(R, "gpurun_out", "final_" + RD); dst = os.path.join(R, "profiles")
-pairs = [("bench.json", RD + "_bench.json"), ("bench_driver_style.json", RD + "_bench_driver_style.json"), (RD + "_pmc.json", RD + "_pmc.json"), ("issue_cost.txt", RD + "_issue_cost.txt")]
+pairs = [("bench.json", RD + "_bench.json"), ("bench_driver_style.json", RD + "_bench_driver_style.json"), (RD + "_pmc.json", RD + "_pmc.json"), ("issue_cost.txt", RD + "_issue_cost.txt"),
+         ("other_configs.txt", RD + "_other_configs.txt"), (os.path.join("..", "pmc_timed_" + RD, RD + "_pmc_timed.json"), RD + "_pmc_timed.json")]
 for tag in ("cornell", "bunny_cornell"):
     pairs += [(f"bench_under_rocprof_{tag}.json", f"{RD}_{tag}_bench_under_rocprof.json")]
     stats = [(f"stats_{tag}", f"{RD}_{tag}_kernel_stats.csv")]

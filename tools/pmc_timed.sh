@@ -9,4 +9,5 @@ cd /tmp && export TMPDIR=/tmp; cd $R
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU --kernel-trace --output-format csv -d $out/pmc -o pmc -- python3 bench.py --lean 1 --cpu-seconds 0 --bvh-scene "" --steps 8 --warmup 2 --profile-steps 1 > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 python3 tools/pmc_timed_sum.py $(find $out/pmc -name "*counter_collection.csv" | head -1) $out/bench.json > profiles/${rd}_pmc_timed.json || exit 1
 find $out -name "*.csv" -size +2M -delete; find $out -name "*.db" -delete
+cp profiles/${rd}_pmc_timed.json $out/${rd}_pmc_timed.json      # (files written outside gpurun_out/ do not come back from the GPU box)
 cat profiles/${rd}_pmc_timed.json
