@@ -316,7 +316,7 @@ class Renderer:
                  graph: bool = False, spp: int = 1, shard=(1, 0), tiles: int = 1, ordered: int = -1):
         """shard = (n, g): iterate(step) renders iteration (step-1)*n + g + 1 of the whole frame (ptk_set_iteration_sharding);
         tiles = K: K bands of rows in flight, bit-identical to the default (ptk_set_tiles_in_flight);
-        ordered: accumulation with several planes (ptk_set_ordered_accumulation; -1 = ordered unless `mode` is MIS)"""
+        ordered: accumulation with several planes (ptk_set_ordered_accumulation; -1 / 1 = ordered, the default; 0 = planes that accumulate)"""
         self.scene = scene
         lib.ptk_pathtrace_free()
         _chk(lib.ptk_set_iteration_sharding(*shard), "ptk_set_iteration_sharding")

@@ -74,7 +74,7 @@ struct RenderContext {
     float* planes = nullptr;            // float[L][spp][3*P]
     float* image = nullptr;             // float[3*P]: the running sum, in iteration order (== planes when there is one plane)
     bool sched_explicit = false;        // ptk_set_iterations_in_flight / _tiles_in_flight / _graph_replay was called: pathtraceInit keeps the caller's schedule
-    int want_ordered = -1;              // ptk_set_ordered_accumulation: -1 auto (ordered unless the sample mode at ptk_pathtrace_init is MIS), 0, 1
+    int want_ordered = -1;              // ptk_set_ordered_accumulation: -1 / 1 ordered (default), 0 planes that accumulate
     bool ordered = false;               // several planes AND ordered accumulation (merge_lane); false: the planes accumulate, resolve_image sums them
     int n_depth = 1;                    // planes per sample: traceDepth + 1 (one per bounce) with ordered accumulation initialised in MIS mode, else 1
     unsigned char* flags = nullptr;     // [L][spp][n_depth][ceil(P / 64)] (ordered accumulation), else null

@@ -70,7 +70,7 @@ def one_case(seed, tmp):
     kw = dict(in_flight=lanes, graph=graph or tiles > 1, pipeline=pipeline, tiles=tiles)
     if part[0] > 1: kw.update(partition=part, spp=spp)
     r = ptk.Renderer(s, mode, **kw)
-    acc = orc.Accumulator(o.P, lanes, spp, mode)          # the product's accumulation policy (ordered unless MIS)
+    acc = orc.Accumulator(o.P, lanes, spp, mode)          # the product's accumulation (ordered; planes per bounce in MIS)
     for it in range(1, iters + 1):
         r.iterate(it)
         if part[0] > 1: _, live = acc.batch(o, mode, it, partition=part)
