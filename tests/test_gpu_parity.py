@@ -654,6 +654,24 @@ def test_iterations_in_flight_keep_the_reference_order(ptk, orc, torch_cuda, nam
     assert np.array_equal(imgs[3], seq), int((imgs[3] != seq).any(axis=1).sum())
 
 
+@pytest.mark.parametrize("name,res,depth,mode,iters", [("cornell.txt", (400, 400), 8, "MIS", 240), ("cornell.txt", None, -1, "BSDF", 96), ("mis_test.txt", (512, 512), 16, "MIS", 240),
+                                                       ("bunny_cornell.txt", (256, 256), 8, "MIS", 60)])
+def test_long_render_in_flight_is_the_one_at_a_time_render(ptk, torch_cuda, name, res, depth, mode, iters):
+    """Product against product, long: hundreds of iterations with three in flight + graph replay (the hints settle, graphs are recaptured, the
+    counts read-backs thin out, `k_tail` takes over) give the SAME image, bit for bit, as one iteration at a time — and as a second run."""
+    m = MODES[mode]
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    imgs = []
+    for lanes in (1, 3, 3):
+        r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
+        for it in range(1, iters + 1):
+            r.iterate(it)
+        imgs.append(r.image()); rays = r.ray_total(); r.close()
+    assert imgs[0].sum() > 0
+    assert np.array_equal(imgs[1], imgs[0]), int((imgs[1] != imgs[0]).any(axis=1).sum())
+    assert np.array_equal(imgs[2], imgs[1])
+
+
 @pytest.mark.parametrize("mode,ordered", [("MIS", 1), ("BSDF", 0), ("MIS", 0), ("DIRECT", -1)])
 def test_accumulation_policy_can_be_forced(ptk, orc, torch_cuda, mode, ordered):
     """ptk_set_ordered_accumulation(-1 / 1 = ordered, the default; 0 = planes that accumulate) — three iterations in flight + graph replay,
