@@ -1,4 +1,5 @@
-"""GPU diagnostic: busy lane share of the wide BVH walk (run with PTK_WIDE_STATS=2; PTK_LIST_SORT=0|1; PTK_WIDE_LPR=2|4).
+"""GPU diagnostic: busy lane share of the wide BVH walk (run with PTK_WIDE_STATS=2; PTK_WIDE_LPR=2|4; the sorted work list it was written
+to judge — PTK_LIST_SORT — was measured and removed in round 4, profiles/r4_lane_busy_sorted_list.txt).
 k_traverse_wide<STATS> adds, per wave, the visits of its slowest ray (what the wave runs for) and the visits of all its rays:
 busy = all visits / (sum of slowest x rays per wave).   usage: lane_busy.py [scene] [iterations]"""
 import importlib, os, sys
@@ -19,6 +20,6 @@ r.sync()
 slow, allv = r.traversal_stats()
 n = r.ray_total() - r0
 G = 64 // lpr
-print(f"sort={os.environ.get('PTK_LIST_SORT', '1')} lpr={lpr}: {n} rays, visits of listed rays {allv}, sum over waves of the slowest ray {slow} "
+print(f"lpr={lpr}: {n} rays, visits of listed rays {allv}, sum over waves of the slowest ray {slow} "
       f"-> busy lane share {allv / max(slow * G, 1):.3f} (rays per wave {G}); wave-visits per traced ray {slow / n:.4f}")
 r.close(); s.close()
