@@ -751,6 +751,10 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
                     // tested at once by the group's lanes without the node fetch, the ordered replay kept for the rare visit with two candidates.
                     // Bit-exact; model chain 9.7 -> 7.7 round trips per ray; one iteration in flight +3 %, three in flight -5.5 %
                     // (profiles/r4_ab_leaf_clusters.txt): n x 64 B and n exact tests per visit instead of 144 B + the ~1.5 leaves the ray meets.)
+                    // (round 4, measured and removed — CAPPED TWO-STAGE WALK: every ray walked for at most 12 loop trips, the unfinished ones parked with hit and
+                    // stack in 128-B records and resumed by a second launch, packed into waves of their own.  Bit-exact; model wave-iterations x 0.68; bunny
+                    // 5.98 -> 5.84 Grays/s, 2048^2 6.56 -> 6.83 (profiles/r4_ab_capped_walk.txt): idle lanes issue no node fetches, the busy lanes' fetches are
+                    // the walk's throughput, and no packing changes their number.)
                     const int nh = __popc(H);
                     if (sp + nh > PTK_WIDE_STACK) { threaded = true; break; }
                     // all hit children at once, in reverse visiting order: the child visited first ends on top
