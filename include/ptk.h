@@ -167,7 +167,8 @@ int ptk_get_sample_mode(void);
  * per launch; needs the fused pipeline 0 / 10).  Every iteration is rendered as K bands of pixel rows on K streams — band k of iteration i beside
  * band k - 1 of iteration i + 1 — so K launches are in flight like with K iterations in flight, but every pixel still receives its iterations in
  * order and every path keeps the reference's RNG key (pathtrace.cu:458,532: a band's compacted slots continue those of the bands above it): the
- * image is BIT-IDENTICAL to the default's, i.e. to the reference's own accumulation order (pathtrace.cu:697-810). */
+ * image is BIT-IDENTICAL to the default's, i.e. to the reference's own accumulation order (pathtrace.cu:697-810), without radiance planes or
+ * merge launches.  (Iterations in flight, below, reach the same image through ordered accumulation and are the faster of the two.) */
 int ptk_set_tiles_in_flight(int tiles);
 /* Iterations in flight (1..16, default 1; set before ptk_pathtrace_init).  With L > 1, the call `step` runs on lane
  * (step-1) % L (own stream, buffers and radiance planes), so consecutive ptk_pathtrace calls overlap on the GPU.  Every

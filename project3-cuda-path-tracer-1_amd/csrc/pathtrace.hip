@@ -647,8 +647,8 @@ int ptk_get_sample_mode(void) { return current_mode(); }
 
 /* Tiles in flight (1..16, default 1 = off; set before ptk_pathtrace_init; not combined with iterations in flight, the tile partition or
  * samples per launch): every iteration is rendered as K bands of rows on K streams, band k of iteration i beside band k - 1 of iteration
- * i + 1 (render_iteration).  Unlike iterations in flight this keeps the reference's accumulation order: the image is bit-identical to
- * the default's. */
+ * i + 1 (render_iteration).  The adds go straight into the one image, in the reference's order — bit-identical to the default's without planes
+ * or merges (iterations in flight reach the same image through ordered accumulation, and are faster: 22 against 14.5 Grays/s on cornell.txt). */
 int ptk_set_tiles_in_flight(int tiles) {
     if (tiles < 1 || tiles > kMaxLanes || g.live) return PTK_E_BADARG;
     g.want_tiles = tiles; g.sched_explicit = true;
