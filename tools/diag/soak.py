@@ -21,7 +21,16 @@ for scn, mode, iters, kw in (("cornell.txt", 0, 3000, dict(in_flight=3, graph=Tr
         r.close(); s.close()
         imgs.append(img)
     ok = np.array_equal(imgs[0], imgs[1]) and np.isfinite(imgs[0]).all() and (imgs[0] >= 0).all()
-    print(f"{scn} mode {mode} {iters} iterations {kw}: {'deterministic' if ok else 'MISMATCH'}, {rays / dt / 1e9:.2f} Grays/s incl. readback, mean radiance {imgs[0].mean() / iters:.5f}")
+    same = ""
+    if kw.get("in_flight", 1) > 1:
+        # round 4, ordered accumulation: the image with iterations in flight IS the image of one iteration at a time, however long the render
+        s = ptk.Scene(os.path.join(ROOT, "scenes", scn))
+        r = ptk.Renderer(s, mode, pipeline=kw.get("pipeline", 0))
+        for it in range(1, iters + 1): r.iterate(it)
+        one = r.image(); r.close(); s.close()
+        eq = np.array_equal(one, imgs[0]); ok = ok and eq
+        same = ", == one iteration at a time" if eq else f", DIFFERS from one iteration at a time in {int((one != imgs[0]).any(axis=1).sum())} pixels"
+    print(f"{scn} mode {mode} {iters} iterations {kw}: {'deterministic' if ok else 'MISMATCH'}{same}, {rays / dt / 1e9:.2f} Grays/s incl. readback, mean radiance {imgs[0].mean() / iters:.5f}")
     assert ok
 
 # graph re-capture with replays in flight: the sample mode flips every 40 iterations with three lanes replaying hipGraphs and no
