@@ -176,7 +176,20 @@ int DevScene::initiate(Scene& scene) {
     // Threaded copies (ptk_device.hpp, "ONE COPY INSTEAD OF SIX"): meshes the render loop walks inside the fused kernel (<= 1 024 triangles, where the
     // nearer-first order is the walk's speed) and meshes without a wide tree keep all six; a large mesh gets the direction-0 copy + the rank table.
     // PTK_THREADED_COPIES=1|6 overrides (tests run both); ptk_set_pipeline(5) / the traversal counters re-upload six (upload_threaded).
-    int copies = (wide_nodes > 0 && tri_num > 1024) ? 1 : 6;
+    // ONE COPY needs more than "large mesh" (ADVICE r4): walking in direction 0's order with the rank tie rule equals the reference's direction-ordered
+    // walk only as long as no leaf is cut (`tEnter > t_min`, pathtrace.cu:253) in one order and tested in the other.  tEnter <= t holds for a
+    // triangle's own box in exact arithmetic; in fp32 it can fail by an ulp where the hit point lies ON a face of the box — for a triangle with an
+    // axis-parallel edge (two vertices sharing a coordinate: the edge lies in that face; a flat box is the extreme case) that is every hit on that
+    // edge, and a hit on a SHARED edge is also where two triangles tie or nearly tie.  Such meshes (tessellated boxes, architecture) keep six copies;
+    // for the others the remaining case is a ray through a vertex to the last bit that also nearly ties with another triangle.
+    bool axis_parallel_edge = false;
+    for (const Triangle& t : scene.triangles) {
+        for (int a = 0; a < 3 && !axis_parallel_edge; ++a)
+            for (int b = a + 1; b < 3; ++b)
+                if (t.v[a].x == t.v[b].x || t.v[a].y == t.v[b].y || t.v[a].z == t.v[b].z) { axis_parallel_edge = true; break; }
+        if (axis_parallel_edge) break;
+    }
+    int copies = (wide_nodes > 0 && tri_num > 1024 && !axis_parallel_edge) ? 1 : 6;
     if (const char* e = getenv("PTK_THREADED_COPIES")) { const int c = atoi(e); if (c == 6 || (c == 1 && tri_num > 0)) copies = c; }
     if ((rc = upload_threaded(scene, copies))) return rc;
     if ((rc = upload(&dev_triv, tv))) return rc;
@@ -215,7 +228,7 @@ int DevScene::upload_threaded(Scene& scene, int copies) {
                 if (n.end - n.start == 1 && n.start >= 0 && n.start < T) ranks[(size_t)d * T + n.start] = r++;
                 i = n.hit;
             }
-            if ((int)r != T) return PTK_E_BADARG;           // not a tree with one triangle per leaf: keep six copies instead
+            if ((int)r != T) return upload_threaded(scene, 6);      // not a tree with one triangle per leaf: keep six copies instead
         }
     }
     void* new_nodes = nullptr; void* new_ranks = nullptr;

@@ -7,11 +7,16 @@
 // binary PPM (P6) and the raw float32 radiance sum (.f32).
 //
 // usage: ptk_headless SCENE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]
-//        [--warmup W] [--no-save] [--in-flight L] [--tiles K] [--graph 0|1] [--eager]
+//        [--warmup W] [--no-save] [--in-flight L] [--tiles K] [--graph 0|1] [--eager] [--reinit-at N]
+//        [--ranks N --rank R --id-file PATH]      (multi-GPU: see "RCCL" below)
+// The loop below is the reference's, call for call: it uses the four reference signatures only and never calls pathtraceResolve() — the library
+// makes scene->state.image current where this loop reads it (round 5: after the call with iteration == state.iterations, and in pathtraceFree;
+// pathtrace.hip).  --iters overrides the scene file's ITERATIONS (state.iterations), as editing the file would.
 // Timing (bench.py `cpp_api`): --warmup W renders W untimed iterations first (then waits for the GPU); the timed region is the remaining
-// pathtrace() calls plus ONE pathtraceResolve() — what a viewer that saves the image at the end pays.  --eager resolves after every call
-// (the reference's pathtrace.cu:809-810 behaviour), --in-flight / --tiles / --graph are the ptk_set_* knobs; without them pathtraceInit chooses
-// (BSDF / DIRECT: 3 in flight + graph replay, image bit-identical to one at a time; MIS: one at a time — pathtrace.hip).
+// pathtrace() calls including the resolve the last one makes — what a viewer that saves the image at the end pays.  --eager = PTK_EAGER_IMAGE=1
+// (the image copied after every call, pathtrace.cu:809-810), --in-flight / --tiles / --graph are the ptk_set_* knobs; without them pathtraceInit
+// chooses three iterations in flight + graph replay with ordered accumulation in every sample mode (image bit-identical to one at a time).
+// --reinit-at N: pathtraceFree() + pathtraceInit() again after iteration N and start over (what the viewer does on a camera / mode change).
 #include "pathtrace.h"
 #include <chrono>
 #include <cmath>
@@ -95,7 +100,7 @@ static void saveImage(const Scene& scene, int iteration, const std::string& base
 
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("Usage: %s SCENEFILE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]\n", argv[0]); return 1; }
-    int iters = -1, rw = -1, rh = -1, depth = -1, warmup = 0, in_flight = 0, graph = -1, tiles = 0;
+    int iters = -1, rw = -1, rh = -1, depth = -1, warmup = 0, in_flight = 0, graph = -1, tiles = 0, reinit_at = 0;
     bool save = true, eager = false;
     std::string out;
     for (int i = 2; i < argc; ++i) {
@@ -111,6 +116,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--tiles") && i + 1 < argc) tiles = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--no-save")) save = false;
         else if (!std::strcmp(argv[i], "--eager")) eager = true;
+        else if (!std::strcmp(argv[i], "--reinit-at") && i + 1 < argc) reinit_at = std::atoi(argv[++i]);
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::printf("No HIP-capable devices were detected.\n"); return 2; }
@@ -125,7 +131,9 @@ int main(int argc, char** argv) {
     InitDataContainer(guiData);
     scene->setDevData();
     if (scene->devError) { std::printf("scene upload failed: %d\n", scene->devError); return 4; }
-    const int total = iters > 0 ? iters : (int)scene->state.iterations;
+    if (iters > 0) scene->state.iterations = iters;     // as if the scene file said ITERATIONS <iters>
+    const int total = (int)scene->state.iterations;
+    if (eager) setenv("PTK_EAGER_IMAGE", "1", 1);
     if (out.empty()) out = scene->state.imageName.empty() ? std::string("render") : scene->state.imageName;
 
     if (in_flight > 0 && ptk_set_iterations_in_flight(in_flight)) { std::printf("bad --in-flight\n"); return 5; }
@@ -138,12 +146,11 @@ int main(int argc, char** argv) {
         if (iteration == 0) { pathtraceFree(); pathtraceInit(scene); }
         if (iteration < total) {
             iteration++; pathtrace(nullptr, 0, iteration);
-            if (eager) pathtraceResolve();               // what the reference does inside pathtrace() (pathtrace.cu:809-810)
-            if (iteration == warmup) { pathtraceResolve(); ptk_get_ray_total(&rays0); t0 = std::chrono::steady_clock::now(); }
+            if (iteration == warmup) { ptk_stream_sync(); ptk_get_ray_total(&rays0); t0 = std::chrono::steady_clock::now(); }
+            if (iteration == reinit_at) { reinit_at = 0; iteration = 0; }      // the viewer's camchanged: runCuda() starts over (main.cpp:173-201)
         }
-        else break;
+        else break;                                      // main.cpp:221-225: saveImage(); pathtraceFree(); exit
     }
-    pathtraceResolve();                                  // scene->state.image and TracedDepth as of the last call (the top of saveImage)
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     unsigned long long rays = 0;
     ptk_get_ray_total(&rays);

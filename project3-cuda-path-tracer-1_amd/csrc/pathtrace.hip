@@ -58,6 +58,7 @@ struct Lane {
     // what this lane renders: the whole frame / this rank's tiles (iterations in flight), or ONE band of rows (tiles in flight)
     int n_parts = 1, part = 0, tile_rows = 1, n_pix = 0, capacity = 0;
     int full_bounces = 0;               // bounces enqueued at full width; the rest of an iteration runs in k_tail (sparse_tail())
+    int traced_depth = 0;               // of the last read-back of this lane's counts (tiles in flight: the viewer's TracedDepth is the maximum over the bands)
     int gen_late = 0;                   // open scene (fewer than ~half of the camera rays hit, learnt like full_bounces): the camera launch stores the hits' path state only
     // tiles in flight: cumulative hit counts [PTK_CUM_RING][traceDepth + 2] (ptk_internal.h: Workspace::cum_*) and one event per ring slot,
     // recorded after this lane's iteration i in slot i % PTK_CUM_RING
@@ -82,7 +83,8 @@ struct RenderContext {
     unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
     int n_parts = 1, part = 0, tile_rows = 1;
-    int pipeline = 0, n_lanes = 1, spp = 1, n_pix = 0;
+    int pipeline = 0, n_lanes = 1, spp = 1, n_pix = 0;      // n_lanes: EFFECTIVE lane count of the live context (iterations in flight, or bands with tiles in flight)
+    int want_lanes = 1;                 // ptk_set_iterations_in_flight: the caller's knob, never overwritten (init / free / init with tiles in flight)
     bool use_graph = false;
     int last_lane = 0;
     int hint_mode = -1;                 // sample mode the lanes' full_bounces / gen_late hints were learnt under
@@ -92,7 +94,8 @@ struct RenderContext {
     bool live = false;
     // C++ API (pathtrace.h): scene->state.image is made current on demand (pathtraceResolve), not after every call
     void* host_image_reg = nullptr;     // state.image's storage, pinned in place (hipHostRegister) so that the D2H copy is one asynchronous DMA
-    bool eager_image = false;           // PTK_EAGER_IMAGE=1: resolve after every pathtrace() call, as pathtrace.cu:809-810 does
+    int image_policy = 0;               // C++ API: 0 = automatic (see pathtrace()), 1 = PTK_EAGER_IMAGE=1: resolve after every call as pathtrace.cu:809-810 does, 2 = PTK_LAZY_IMAGE=1: only pathtraceResolve()
+    bool host_image_stale = false;      // a pathtrace() call was enqueued since scene->state.image was last made current
 } g;
 
 int g_mode_override = -1;               // ptk_set_sample_mode; -1 = follow the `sampleMode` global
@@ -145,7 +148,7 @@ int context_free() {
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
     if (g.resolved) { (void)hipEventDestroy(g.resolved); g.resolved = nullptr; }
     g.last_merged = nullptr; g.ordered = false; g.n_depth = 1;
-    g.live = false; g.tiles = false; g.scene = nullptr; g.P = g.capacity = 0;
+    g.live = false; g.tiles = false; g.n_lanes = g.want_lanes; g.scene = nullptr; g.P = g.capacity = 0;
     return 0;
 }
 
@@ -263,6 +266,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.inline_bvh = inline_bvh_choice(g.pipeline);
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.wide_lpr = pick_lpr(g.n_lanes);            // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
+    l.ws.wide_pool = pick_wide_pool(l.capacity, g.tiles ? 1 : g.n_lanes);
     l.ws.capacity = l.capacity;
     l.last_iter = 0;
     return 0;
@@ -293,8 +297,9 @@ int context_init(Scene* scene) {
     if ((e = hipEventCreateWithFlags(&g.resolved, hipEventDisableTiming)) != hipSuccess) return (int)e;
     // tiles in flight: as many lanes as there are non-empty bands of ceil(H / K) rows; one shared radiance plane
     g.tiles = g.want_tiles > 1;
+    g.n_lanes = g.want_lanes;
     if (g.tiles) {
-        if (g.n_lanes != 1 || g.n_parts != 1 || g.spp != 1) return PTK_E_BADARG;       // (not combined with iterations in flight / the multi-GPU tile partition / samples per launch)
+        if (g.want_lanes != 1 || g.n_parts != 1 || g.spp != 1) return PTK_E_BADARG;       // (not combined with iterations in flight / the multi-GPU tile partition / samples per launch)
         if (!trace_pipeline(g.pipeline)) return PTK_E_BADARG;                           // (only the fused launches carry the bands' cumulative hit counts)
         const int rows = (cam.resolution.y + g.want_tiles - 1) / g.want_tiles;
         g.n_lanes = (cam.resolution.y + rows - 1) / rows;
@@ -431,7 +436,12 @@ constexpr int kTailPaths = 1024;                 // a bounce with at most this m
 void note_counts(Lane& L) {
     if (!L.counts_pending || hipEventQuery(L.counts_ev) != hipSuccess) return;
     L.counts_pending = false;
-    if (g.gui) { int d = 0; while (d < g.traceDepth && L.h_counts[d] > 0) ++d; g.gui->TracedDepth = d; }      // pathtrace.cu:793-796, one read-back late
+    if (g.gui) {                                                       // pathtrace.cu:793-796, one read-back late
+        int d = 0; while (d < g.traceDepth && L.h_counts[d] > 0) ++d;
+        L.traced_depth = d;
+        if (g.tiles) for (const Lane& o : g.lanes) d = std::max(d, o.traced_depth);      // a band is a part of the frame: the frame's depth is the deepest band's
+        g.gui->TracedDepth = d;
+    }
     if (!sparse_tail()) return;
     // what k_tail looks at in its first bounce: the live paths — or, after a hit-dense launch, only the paths that hit something (mis_test.txt:
     // 1 088 live but 43 hits at bounce 2: the tail takes over one 20-us launch earlier)
@@ -610,7 +620,8 @@ int resolve_image() {
 // asynchronous readers on lane 0 were enqueued (the plane sum above, the tone map of ptk_pathtrace): the other lanes' next launches write the
 // planes / merge into the image they read — they wait for them (event edge, no host wait)
 int image_reader_enqueued() {
-    if (g.n_lanes == 1 || g.image == g.planes) return 0;
+    // (tiles in flight: one shared plane that bands 1..K-1 keep adding the NEXT iteration into — the tone map must have read it first)
+    if (g.n_lanes == 1 || (g.image == g.planes && !g.tiles)) return 0;
     const hipError_t e = hipEventRecord(g.resolved, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
     for (size_t i = 1; i < g.lanes.size(); ++i) g.lanes[i].wait_resolved = true;
@@ -665,7 +676,7 @@ int ptk_set_ordered_accumulation(int on) {
 }
 int ptk_set_iterations_in_flight(int lanes) {
     if (lanes < 1 || lanes > kMaxLanes || g.live) return PTK_E_BADARG;     // set before ptk_pathtrace_init
-    g.n_lanes = lanes; g.sched_explicit = true;
+    g.want_lanes = lanes; g.sched_explicit = true;
     return 0;
 }
 
@@ -906,15 +917,16 @@ void pathtraceInit(Scene* scene) {
     if (!g.live) {
         const bool env_sched = getenv("PTK_IN_FLIGHT") || getenv("PTK_TILES") || getenv("PTK_GRAPH");
         if (!g.sched_explicit && !env_sched) {
-            g.n_lanes = 3; g.use_graph = true; g.want_tiles = 1;
+            g.want_lanes = 3; g.use_graph = true; g.want_tiles = 1;
         }
-        if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.n_lanes = l; }
+        if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.want_lanes = l; }
         if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;
         if (const char* e = getenv("PTK_TILES")) { const int t = atoi(e); if (t >= 1 && t <= kMaxLanes) g.want_tiles = t; }
         if (const char* e = getenv("PTK_ORDERED")) { const int o = atoi(e); if (o >= -1 && o <= 1) g.want_ordered = o; }
     }
     PTK_CHECK("pathtraceInit", context_init(scene));
-    g.eager_image = getenv("PTK_EAGER_IMAGE") && atoi(getenv("PTK_EAGER_IMAGE")) != 0;
+    g.image_policy = (getenv("PTK_EAGER_IMAGE") && atoi(getenv("PTK_EAGER_IMAGE")) != 0) ? 1 : ((getenv("PTK_LAZY_IMAGE") && atoi(getenv("PTK_LAZY_IMAGE")) != 0) ? 2 : 0);
+    g.host_image_stale = false;
     // the host image lives where the reference keeps it; pinned in place, so that pathtraceResolve's copy is one asynchronous DMA.  The
     // reference never resizes it after pathtraceInit (main.cpp:146-170 only reads it); if pinning fails the copy is a plain pageable one.
     std::vector<ptk::vec3>& img = scene->state.image;
@@ -923,7 +935,11 @@ void pathtraceInit(Scene* scene) {
     else (void)hipGetLastError();
 }
 
-void pathtraceFree() { PTK_CHECK("pathtraceFree", context_free()); }
+// (the reference's state.image is current at any time, so a caller may read it after pathtraceFree: make it so before the device image goes)
+void pathtraceFree() {
+    if (g.live && g.host_image_stale && g.image_policy != 2) pathtraceResolve();
+    PTK_CHECK("pathtraceFree", context_free());
+}
 
 // Not a reference function.  scene->state.image (the running radiance SUM, pathtrace.cu:809-810) and guiData->TracedDepth
 // (pathtrace.cu:793-796) as of the last pathtrace() call; waits for the GPU.  SURVEY 8(b) "Outputs": the per-iteration D2H may be lazy as
@@ -938,6 +954,7 @@ void pathtraceResolve() {
         else (void)hipGetLastError();
     }
     PTK_CHECK("pathtraceResolve", ptk_get_image(reinterpret_cast<float*>(img.data())));
+    g.host_image_stale = false;
     if (g.gui) {
         std::vector<int> counts((size_t)g.traceDepth + 1);
         int depth = 0;
@@ -946,9 +963,17 @@ void pathtraceResolve() {
     }
 }
 
+// The reference refreshes scene->state.image after EVERY call (pathtrace.cu:809-810) and its caller reads it with no hook (saveImage, main.cpp:146-170).
+// Default policy (round 5) — correct for an UNEDITED caller, at the overlapped speed where that matters:
+//   * pbo != nullptr (the viewer's loop, main.cpp:205-219: one call per displayed frame, and the S key may save at any time): resolve after every
+//     call, as the reference does;
+//   * pbo == nullptr (headless callers): enqueue only — no host wait, no D2H — and resolve after the call with iteration >= state.iterations, the one
+//     after which main.cpp:221-222 saves and exits, and in pathtraceFree().  TracedDepth follows from the asynchronous counts read-back (note_counts),
+//     a call or more late, and is exact after a resolve.
+// pathtraceResolve() remains for a headless caller that reads the image earlier; PTK_EAGER_IMAGE=1 / PTK_LAZY_IMAGE=1 force either behaviour.
 void pathtrace(uchar4* pbo, int frame, int iteration) {
-    // enqueue only: no host wait, no D2H.  TracedDepth follows from the asynchronous counts read-back (note_counts), a call or more late;
-    // pathtraceResolve() makes both exact.
     PTK_CHECK("pathtrace", ptk_pathtrace(reinterpret_cast<unsigned char*>(pbo), frame, iteration));
-    if (g.eager_image) pathtraceResolve();
+    g.host_image_stale = true;
+    const bool last_call = g.scene && iteration >= g.scene->state.iterations;
+    if (g.image_policy == 1 || (g.image_policy == 0 && (pbo != nullptr || last_call))) pathtraceResolve();
 }

@@ -811,6 +811,140 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_traverse_pool (round 5): the same 8-wide walk, with the rays of a block POOLED.  k_traverse_wide gives every group of LPR lanes one ray and a
+// wave runs until its slowest ray is done: with 32 rays per wave the wave-iterations are 2.8 x the lane work (busy lane share 0.36; mean 9 loop trips
+// per ray, 99th percentile 31, slowest 80-90 — tools/diag/wide_tree_stats.py) and, with several iterations in flight, vector-ALU issue is what the
+// walk costs.  Here a block of 256 threads stages a chunk of `chunk` consecutive work-list rays in LDS (one coalesced pass; a refill is an LDS read,
+// not a chain of three dependent global loads) and its groups take the next ray from a block counter whenever a quarter of a wave's lanes have
+// gone idle (all idle groups of the wave at once: the refill code runs once per ~2.5 loop trips, not in every trip for one or two groups — the
+// persistent-threads scheme of Aila & Laine, "Understanding the efficiency of ray traversal on GPUs", HPG 2009, at group granularity).  CPU model:
+// 0.58 (chunk 512) / 0.51 (1 024) of k_traverse_wide's wave-iterations.  Every ray runs exactly the loop of k_traverse_wide — same node / leaf
+// visits in the same order, same fallbacks — so the results are bit-identical by construction; only which lanes walk which ray changes.
+// LDS: rays 32 B x chunk + stacks 12.8 KB + staged top nodes 2.3 KB (chunk 512: 31 KB, five blocks per CU).
+// ------------------------------------------------------------------------------------------------------------------
+#define PTK_POOL_IDLE_LANES 16    // a wave refills when at least this many of its 64 lanes are idle
+template <int LPR>
+__global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_pool(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
+                                                              PtkPaths paths, PtkHits hits, int* __restrict__ valid, const int* __restrict__ srcidx, int chunk) {
+    constexpr int GROUPS = PTK_WIDE_BLOCK / LPR, NCH = 8 / LPR;
+    __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
+    __shared__ unsigned s_stack[GROUPS * PTK_WIDE_STRIDE];
+    __shared__ int s_next;
+    extern __shared__ float4 s_rays[];                           // [chunk][2]: (origin, t0), (direction, ray index)
+    const int m = (int)*list_count;
+    const int j0 = blockIdx.x * chunk;
+    if (j0 >= m) return;
+    const int cnt = m - j0 < chunk ? m - j0 : chunk;
+    const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
+    for (int k = threadIdx.x; k < n_top * 9; k += PTK_WIDE_BLOCK) s_top[k] = S.wnodes[k];
+    for (int k = threadIdx.x; k < cnt; k += PTK_WIDE_BLOCK) {
+        const int ray = list[j0 + k];
+        const int src = srcidx ? srcidx[ray] : ray;
+        const float4 o4 = ld4(paths.o_pix, src), d4 = ld4(paths.d_bnc, src);
+        s_rays[2 * k] = make_float4(o4.x, o4.y, o4.z, hits.t_n[4 * (size_t)ray]);
+        s_rays[2 * k + 1] = make_float4(d4.x, d4.y, d4.z, __int_as_float(ray));
+    }
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+    const int q = threadIdx.x & (LPR - 1);
+    const int leader = (threadIdx.x & 63) & ~(LPR - 1);            // first lane of the group within the wave
+    unsigned* stk = s_stack + (threadIdx.x / LPR) * PTK_WIDE_STRIDE;
+    WideRay r; WideFrame f;
+    r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0); r.inv = mk3(0, 0, 0); r.t_min = 0.f; r.tri = -1; r.u = 0.f; r.v = 0.f; r.dir = 0; f.selN = f.selF = 0u;
+    int ray = -1, sp = 0;
+    float t_init = 0.f;
+    unsigned cur = 0u;
+    bool active = false, pool_empty = false;                     // pool_empty is wave-uniform
+    for (;;) {
+        // ---- refill: a wave-uniform decision; all idle groups of the wave draw at once (the first pass hands every group its first ray)
+        const int n_idle = 64 - __popcll(__ballot(active));
+        if (n_idle >= PTK_POOL_IDLE_LANES && !pool_empty) {
+            if (!active) {
+                int j = 0;
+                if (q == 0) j = atomicAdd(&s_next, 1);
+                j = __shfl(j, leader, 64);
+                if (j < cnt) {
+                    const float4 a = s_rays[2 * j], b = s_rays[2 * j + 1];
+                    r.o = mk3(a.x, a.y, a.z); r.d = mk3(b.x, b.y, b.z); ray = __float_as_int(b.w);
+                    r.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                    r.t_min = a.w > 0.f ? a.w : FLT_MAX; r.tri = -1; r.u = 0.f; r.v = 0.f;
+                    r.dir = mtbvh_dir(r.d);
+                    t_init = r.t_min;
+                    wide_frame_selectors(r.inv.x > 0.f, r.inv.y > 0.f, r.inv.z > 0.f, f);
+                    sp = 0; active = true;
+                    // the fast slab test needs finite non-zero 1/d (Bounds3.hpp:174-177 otherwise): such rays take the reference's own walk at once
+                    cur = (fabsf(r.d.x) >= 1e-30f && fabsf(r.d.y) >= 1e-30f && fabsf(r.d.z) >= 1e-30f) ? 0u : 0xffffffffu;
+                }
+            }
+            pool_empty = __any(!active);                         // a group drew past the end of the chunk (s_next only grows)
+        }
+        if (__ballot(active) == 0ull) break;                     // every group idle: the pool is empty (otherwise the refill above made one busy)
+        if (active) {
+            // ---- one loop trip of k_traverse_wide for this group's ray
+            bool finished = false, overflow = false;
+            if (cur == 0xffffffffu) {                            // the reference's own walk (zero direction component, or the stack would overflow)
+                Walk w;
+                walk_begin(S, r.o, r.d, t_init, w);
+                while (w.idx != -1) (void)walk_step(S, w);
+                r.tri = w.tri; r.u = w.u; r.v = w.v; r.t_min = w.t_min;
+                finished = true;
+            } else if (!(cur & PTK_WIDE_LEAF)) {
+                uint4 q0, ch[NCH];
+                if (PTK_WIDE_TOP > 0 && (int)cur < n_top) {
+                    const uint4* np = s_top + cur * 9; q0 = np[0];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
+                    asm volatile("" : "+v"(q0.x), "+v"(ch[0].x));
+                } else {
+                    const uint4* np = S.wnodes + (size_t)cur * 9; q0 = np[0];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
+                    asm volatile("" : "+v"(q0.x), "+v"(ch[0].x));
+                }
+                const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+                f.Ax = sx * r.inv.x; f.Ay = sy * r.inv.y; f.Az = sz * r.inv.z;
+                const float Bx = (__uint_as_float(q0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(q0.y) - r.o.y) * r.inv.y, Bz = (__uint_as_float(q0.z) - r.o.z) * r.inv.z;
+                const float K = 9.5367431640625e-07f, K255 = 255.f * K;            // same margins as k_traverse_wide
+                const float mx = __builtin_fmaf(K255, fabsf(f.Ax), __builtin_fmaf(K, fabsf(Bx), 1e-36f)), my = __builtin_fmaf(K255, fabsf(f.Ay), __builtin_fmaf(K, fabsf(By), 1e-36f)),
+                            mz = __builtin_fmaf(K255, fabsf(f.Az), __builtin_fmaf(K, fabsf(Bz), 1e-36f));
+                f.Bnx = Bx - mx; f.Bfx = Bx + mx; f.Bny = By - my; f.Bfy = By + my; f.Bnz = Bz - mz; f.Bfz = Bz + mz;
+                const int nc = (int)(q0.w >> 24);
+                bool hit[NCH];
+                unsigned H = 0u;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    hit[k] = (q + LPR * k < nc) & wide_child_test(ch[k], f, r.t_min);
+                    H |= hit[k] ? (1u << (q + LPR * k)) : 0u;
+                }
+                H = wide_group_or<LPR>(H);
+                const int nh = __popc(H);
+                overflow = sp + nh > PTK_WIDE_STACK;             // (the threaded walk starts over from t_init: same result by construction)
+                if (!overflow) {
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k)
+                        if (hit[k]) stk[sp + nh - 1 - __popc(H & wide_before(ch[k], r.dir))] = ch[k].w;
+                    sp += nh;
+                    finished = sp == 0;
+                }
+            } else {
+                const uint4* lp = S.wleaves + (size_t)(cur & ~PTK_WIDE_LEAF) * 4;
+                const uint4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
+                (void)wide_leaf_visit(l0, l1, l2, l3, r);
+                finished = sp == 0;
+            }
+            if (overflow) cur = 0xffffffffu;
+            else if (finished) {
+                if (q == 0 && r.tri >= 0) {
+                    st4(hits.uv_ids, ray, make_float4(r.u, r.v, r.t_min, __int_as_float(r.tri)));
+                    valid[ray] = PTK_VALID_TRI;
+                }
+                active = false;
+            } else { --sp; cur = stk[sp]; }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(PTK_BLOCK) k_finalize(SceneView S, int n_arg, const int* __restrict__ d_n, PtkHits hits,
                                                          int* __restrict__ valid, int* __restrict__ agg) {
     const int n = d_n ? *d_n : n_arg;
@@ -2141,6 +2275,21 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_exact_check(unsigned long long n,
 #endif // PTK_TEST_HOOKS
 
 inline int grid_for(int n) { return (n + PTK_BLOCK - 1) / PTK_BLOCK; }
+
+// The 8-wide walk of the work-list rays (g = blocks of 256 stream slots the list may cover).  pool > 0: k_traverse_pool with chunks of `pool` rays
+// per block; 0: k_traverse_wide, one ray per group of lpr lanes.  Bit-identical hits either way (pick_wide_pool below chooses).
+static void launch_wide_walk(const SceneView& S, int g, int lpr, int pool, const unsigned* queue, const int* list, PtkPaths paths, PtkHits hits, int* valid,
+                             const int* srcidx, hipStream_t st) {
+    if (pool > 0) {
+        const int blocks = (g * PTK_BLOCK + pool - 1) / pool;
+        const size_t lds = (size_t)pool * 2 * sizeof(float4);
+        if (lpr == 2) k_traverse_pool<2><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
+        else k_traverse_pool<4><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
+        return;
+    }
+    if (lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, paths, hits, valid, nullptr, srcidx);
+    else k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, paths, hits, valid, nullptr, srcidx);
+}
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 inline int launch_rc() { return hip_rc(hipGetLastError()); }
 
@@ -2188,6 +2337,15 @@ int g_compact_agg_cap = 0;
 // ------------------------------------------------------------------------------------------------------------------
 namespace ptk {
 
+// Pooled wide walk or not (k_traverse_pool).  Measured on the bunny scene, Grays/s, three iterations in flight, k_traverse_wide / pool 256 / 512 /
+// 1 024 (profiles/r5_ab_pooled_walk.txt): 800 x 800 depth 8 (142 k listed rays per launch): 6.12 / 6.01 / 5.62 / 4.39 — too few rays to keep the
+// machine in waves once four share a group; one iteration at a time 3.48 / 2.67 / 2.02 / 1.28; 2 048 x 2 048 depth 16 (0.9 M listed rays): 6.67 /
+// 6.91 / 7.08 / 6.53.  Hence: pools of 512 from two million paths per launch on, and only with iterations in flight.  PTK_WIDE_POOL=<n> forces a
+// chunk (0 = off) for A/B runs and the parity tests.
+int pick_wide_pool(int capacity, int n_lanes) {
+    if (const char* e = getenv("PTK_WIDE_POOL")) { const int v = atoi(e); return v < 0 ? 0 : (v > 2048 ? 2048 : v); }
+    return (n_lanes > 1 && capacity >= (1 << 21)) ? 512 : 0;
+}
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows) {
     if (n_parts <= 1) return W * H;
     int rows = 0;
@@ -2213,7 +2371,7 @@ int launch_generate(const ::Camera& cam, int iter, const int* iter_ptr, int trac
 // intersection stage (any of the layouts above), asynchronous on `st`.  agg may be null (kernel-level ABI).
 int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths cur, PtkHits hits, int* valid, int* agg,
                            unsigned long long* ray_total, unsigned long long* stats, unsigned* queue, int* list, int* hflag, int* hagg,
-                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED, int wide_lpr = 4) {
+                           bool inline_bvh, hipStream_t st, void (*mark)(int, bool), const Gather& G, int walk = PTK_WALK_THREADED, int wide_lpr = 4, int wide_pool = 0) {
     const int g = grid_for(n);
     if (g == 0) return 0;
     const bool split = S.n_tris > 0 && !inline_bvh && queue != nullptr && list != nullptr && hflag != nullptr && hagg != nullptr;
@@ -2234,8 +2392,7 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
     if (wide && stats && wide_stats && wide_lpr == 2) k_traverse_wide<true, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
     else if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
-    else if (wide && !stats && wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
-    else if (wide && !stats) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
+    else if (wide && !stats) launch_wide_walk(S, g, wide_lpr, wide_pool, queue, list, cur, hits, valid, G.src, st);
     else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);
     else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, nullptr, G.src);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
@@ -2262,7 +2419,7 @@ int launch_bounce_staged_profiled(const SceneView& S_in, int mode, int iter, int
     if (depth > 0) { G.pref = ws.seg_pref; G.first = ws.seg_first; G.src = ws.srcidx; }
     // the shading stage's flag/aggregate arrays are free during the intersection stage: they carry the work-list flags
     int rc = launch_intersect_stage(S, capacity, d_n, cur, hits, ws.valid_a, ws.agg_a, ws.ray_total, ws.stats, ws.queue, ws.list,
-                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr);
+                                    ws.valid_b, ws.agg_b, ws.inline_bvh, st, mark, G, ws.walk, ws.wide_lpr, ws.wide_pool);
     if (rc) return rc;
     if (S.env_tex >= 0) {
         k_env_miss<<<g, PTK_BLOCK, 0, st>>>(S, capacity, d_n, cur, ws.valid_a, film_of(img, ws), depth, G.src);
@@ -2353,8 +2510,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
         const bool wide = ws.walk == PTK_WALK_WIDE && S.wnodes;
         k_list<<<g, PTK_BLOCK, 0, st>>>(n_bound, d_n, ws.tr_heavy, ws.agg_a, ws.list, ws.queue, 1);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
-        if (wide && ws.wide_lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
-        else if (wide) k_traverse_wide<false, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
+        if (wide) launch_wide_walk(S, g, ws.wide_lpr, ws.wide_pool, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, st);
         else k_traverse<false><<<g, PTK_BLOCK, 0, st>>>(S, ws.queue, ws.list, nxt.paths, nxt.hits, ws.tr_valid, nullptr, nullptr);
         if ((rc = launch_rc())) { mark(1, false); return rc; }
         k_finalize2<<<g, PTK_BLOCK, 0, st>>>(S, n_bound, d_n, nxt.hits, ws.tr_valid, nxt.hr, ws.agg_h, ws.seg_done, ws.hit_pref,
@@ -2451,7 +2607,7 @@ int ptk_intersect(const PtkScene* s, int n, const int* d_n, PtkPaths paths, PtkH
     // the render loop's own layout: analytic primitives + root-box test, work list, BVH walk (the 8-wide collapsed tree; with `stats`
     // the reference's threaded walk, whose visits the counters describe), finalize
     int rc = launch_intersect_stage(S, n, d_n, paths, hits, valid, nullptr, nullptr, stats, g_abi_queue, g_abi_list,
-                                    g_abi_hflag, g_abi_hagg, false, (hipStream_t)stream, [](int, bool) {}, Gather{nullptr, nullptr, nullptr}, PTK_WALK_WIDE, 4);
+                                    g_abi_hflag, g_abi_hagg, false, (hipStream_t)stream, [](int, bool) {}, Gather{nullptr, nullptr, nullptr}, PTK_WALK_WIDE, 4, pick_wide_pool(0, 1));
     if (rc || !img || S.env_tex < 0) return rc;
     if (!paths.col_pdf) return PTK_E_BADARG;
     k_env_miss<<<grid_for(n), PTK_BLOCK, 0, (hipStream_t)stream>>>(S, n, d_n, paths, valid, FilmArgs{img, nullptr, 0u, 0u, 0u, 0u}, 0, nullptr);

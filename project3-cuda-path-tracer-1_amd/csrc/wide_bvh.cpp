@@ -3,6 +3,7 @@
 #include "wide_bvh.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 
@@ -52,6 +53,49 @@ void order_slots(const Topo& T, int d, int i, const std::vector<int>& slot_of, s
 
 float comp(const vec3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
+// Which frontier of the binary tree becomes the children of a wide node.  Any frontier is parity-preserving (wide_bvh.h); this picks the one
+// that minimises the expected number of node visits of a random ray — the surface-area measure the reference's own builder uses
+// (BVH.cpp:36-75) — by dynamic programming over the binary tree, bottom-up:
+//   node(i)    = area(i) + slots(i, 8)                      a wide node rooted at inner node i: it is visited with probability ~ area(i)
+//   slots(i,1) = leaf(i) ? 0 : node(i)                      subtree i behind ONE child slot (a leaf slot costs the same in every collapse)
+//   slots(i,k) = min(slots(i,k-1), min_j slots(L,j) + slots(R,k-j))
+// (the collapse of Ylitie, Karras, Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", HPG 2017, section 4.1, with
+// one triangle per leaf as in the reference).  Round 5: the greedy "open the largest child" expansion it replaces left the bunny's nodes 4.1 / 8
+// full (3 202 nodes, 6 levels): every small subtree that reached a frontier became a node of its own.
+// PTK_WIDE_COLLAPSE=greedy: the round-2 expansion (largest-area child first), kept for A/B measurements; anything else: the plan below
+int collapse_mode() { const char* e = std::getenv("PTK_WIDE_COLLAPSE"); return (e && std::strcmp(e, "greedy") == 0) ? 0 : 1; }
+
+struct CollapsePlan {
+    bool on = false;
+    std::vector<double> open;        // [B][9]: cost of subtree i OPENED into <= k slots (k = 2..8; its two children share them), non-increasing in k
+    std::vector<double> node;        // [B]: cost of subtree i as a wide node of its own (behind one slot); 0 for a leaf
+    std::vector<uint8_t> split;      // [B][9]: slots given to the left child when i is opened into exactly k
+    void solve(const Topo& T, double node_bias) {
+        open.assign((size_t)T.B * 9, 0.0); node.assign(T.B, 0.0); split.assign((size_t)T.B * 9, 0);
+        auto slots = [&](int i, int k) { return T.leaf(i) ? 0.0 : (k == 1 ? node[i] : std::min(node[i], open[(size_t)i * 9 + k])); };
+        for (int i = T.B - 1; i >= 0; --i) {                 // preorder array: children come later
+            if (T.leaf(i)) continue;
+            const int L = T.left(i), R = T.right(i);
+            double* o = &open[(size_t)i * 9]; uint8_t* sp = &split[(size_t)i * 9];
+            for (int k = 2; k <= 8; ++k) {
+                double best = 1e300; int bj = 1;
+                for (int j = 1; j < k; ++j) { const double c = slots(L, j) + slots(R, k - j); if (c < best) { best = c; bj = j; } }
+                if (k > 2 && o[k - 1] <= best) { o[k] = o[k - 1]; sp[k] = 0; }       // 0: no better than with one slot less — use that plan
+                else { o[k] = best; sp[k] = (uint8_t)bj; }
+            }
+            node[i] = T.area(i) + node_bias + o[8];
+        }
+        on = true;
+    }
+    void expand(const Topo& T, int i, int k, bool forced, std::vector<int>& fr) const {
+        if (T.leaf(i) || k == 1 || (!forced && node[i] <= open[(size_t)i * 9 + k])) { fr.push_back(i); return; }
+        while (split[(size_t)i * 9 + k] == 0) --k;
+        const int j = split[(size_t)i * 9 + k];
+        expand(T, T.left(i), j, false, fr); expand(T, T.right(i), k - j, false, fr);
+    }
+    void cut(const Topo& T, int r, std::vector<int>& fr) const { expand(T, r, 8, true, fr); }
+};
+
 } // namespace
 
 bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<Triangle>& tris, WideBvh& out) {
@@ -61,6 +105,8 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
     struct Pending { int root; int level; };
     std::deque<Pending> queue;
     queue.push_back({0, 0});
+    CollapsePlan plan;
+    if (collapse_mode() != 0) { const char* e = std::getenv("PTK_WIDE_NODE_BIAS"); plan.solve(T, (e ? std::atof(e) : 0.0) * T.area(0)); }
     std::vector<int> slot_of(B, -1);
     std::vector<int> node_root;                      // binary root of every wide node (for the stack bound)
     std::vector<std::vector<int>> kids;              // inner children (wide indices) per wide node
@@ -72,6 +118,7 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
         out.depth = std::max(out.depth, cur.level + 1);
         std::vector<int> fr;
         if (T.leaf(r)) fr.push_back(r);
+        else if (plan.on) plan.cut(T, r, fr);
         else {
             fr.push_back(T.left(r)); fr.push_back(T.right(r));
             while (fr.size() < 8) {

@@ -232,6 +232,44 @@ def test_wide_walk_equals_threaded_walk_full_size(ptk, torch_cuda, name, mode):
         assert np.array_equal(out[(10, lanes)][0], out[(6, lanes)][0]), int((out[(10, lanes)][0] != out[(6, lanes)][0]).any(axis=1).sum())
 
 
+@pytest.mark.parametrize("mode,pipeline", [("BSDF", 0), ("MIS", 0), ("BSDF", 10)])
+def test_pooled_walk_equals_one_ray_per_group(ptk, orc, torch_cuda, monkeypatch, mode, pipeline):
+    """Round 5: k_traverse_pool (a block's groups draw work-list rays from a pool staged in LDS and refill when a quarter of a wave is idle) walks
+    every ray exactly like k_traverse_wide does — only which lanes walk which ray changes.  Radiance and live counts with pools of 64 (every block
+    starts half empty), 512 and 2 048 rays == one ray per group == the oracle, one and three iterations in flight; the automatic choice (pools from
+    two million paths per launch on, with iterations in flight) is checked on the 2048 x 2048 frame of BASELINE configs[4] against pools switched off."""
+    path = os.path.join(SC, "bunny_cornell.txt")
+    res, depth = (200, 168), 6
+    o = orc.Scene(path, res=res, depth=depth)
+    ref = np.zeros((o.P, 3), np.float32); lives = []
+    for it in (1, 2, 3, 4):
+        lives.append(o.pathtrace(MODES[mode], it, ref)[1].copy())
+    for pool in ("0", "64", "512", "2048"):
+        monkeypatch.setenv("PTK_WIDE_POOL", pool)
+        for lanes in (1, 3):
+            s = ptk.Scene(path, res=res, depth=depth)
+            r = ptk.Renderer(s, MODES[mode], pipeline=pipeline, in_flight=lanes, graph=lanes > 1)
+            got = []
+            for it in (1, 2, 3, 4):
+                r.iterate(it); got.append(r.live_counts()[0].copy())
+            img = r.image(); r.close(); s.close()
+            assert np.array_equal(np.stack(got), np.stack(lives)), (pool, lanes)
+            assert np.array_equal(img, ref), (pool, lanes, int((img != ref).any(axis=1).sum()))
+
+
+def test_pooled_walk_is_the_choice_at_2048(ptk, torch_cuda, monkeypatch):
+    out = {}
+    for pool in (None, "0"):
+        if pool is None: monkeypatch.delenv("PTK_WIDE_POOL", raising=False)
+        else: monkeypatch.setenv("PTK_WIDE_POOL", pool)
+        s = ptk.Scene(os.path.join(SC, "bunny_cornell.txt"), res=(2048, 2048), depth=16)
+        r = ptk.Renderer(s, MODES["BSDF"], in_flight=3, graph=True)
+        for it in (1, 2, 3):
+            r.iterate(it)
+        out[pool] = (r.image(), r.live_counts()[0].copy()); r.close(); s.close()
+    assert out[None][0].any() and np.array_equal(out[None][1], out["0"][1]) and np.array_equal(out[None][0], out["0"][0])
+
+
 @pytest.mark.parametrize("name,res,depth,mode,lanes", [("mis_test.txt", (512, 512), 16, "MIS", 1), ("mis_test.txt", (512, 512), 16, "BSDF", 3),
                                                        ("mis_test2.txt", (256, 256), 12, "DIRECT", 1), ("bunny_cornell.txt", (40, 40), 10, "MIS", 1),
                                                        ("cornell.txt", (24, 24), 8, "BSDF", 3)])
@@ -385,12 +423,17 @@ def test_headless_driver(ptk, orc, torch_cuda, tmp_path):
 
 
 @pytest.mark.parametrize("mode,flags,lanes", [("mis", (), 3), ("mis", ("--eager",), 3), ("mis", ("--in-flight", "1", "--graph", "0"), 1),
-                                              ("bsdf", (), 3), ("bsdf", ("--in-flight", "1", "--graph", "0"), 1), ("direct", (), 3)])
-def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, mode, flags, lanes):
-    """The C++ pathtrace() only enqueues (no D2H, no host wait, SURVEY 8b "Outputs"); pathtraceResolve() makes scene->state.image and
-    TracedDepth current: 6 back-to-back pathtrace() calls + ONE resolve == the oracle's PLAIN SEQUENTIAL render, bit for bit, in every sample
-    mode — at the API's defaults (three iterations in flight + graph replay, ordered accumulation), with a resolve after every call
-    (--eager = pathtrace.cu:809-810) and in the explicit one-at-a-time schedule."""
+                                              ("bsdf", (), 3), ("bsdf", ("--in-flight", "1", "--graph", "0"), 1), ("direct", (), 3),
+                                              ("bsdf", ("--tiles", "3", "--reinit-at", "2"), 3), ("mis", ("--reinit-at", "4"), 3),
+                                              ("mis", ("--tiles", "4", "--reinit-at", "1"), 4)])
+def test_cpp_api_unedited_caller(orc, torch_cuda, tmp_path, mode, flags, lanes):
+    """The drop-in contract for an UNEDITED caller (SURVEY 8b "Outputs").  ptk_headless is the reference's loop call for call — the
+    four reference signatures only, NO pathtraceResolve() — and saveImage() reads scene->state.image right after the loop: 6 back-to-back
+    pathtrace() calls == the oracle's PLAIN SEQUENTIAL render, bit for bit, in every sample mode — at the API's defaults (three iterations in
+    flight + graph replay, ordered accumulation; the library resolves inside the call with iteration == state.iterations), with a copy after
+    every call (--eager = pathtrace.cu:809-810) and in the explicit one-at-a-time schedule.  --reinit-at N: pathtraceFree() + pathtraceInit()
+    after iteration N and start over, what the viewer does on a camera or mode change — with tiles in flight that used to abort on the second
+    init (the band count had overwritten the lane knob)."""
     import subprocess
     exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
     base = str(tmp_path / "lazy")
@@ -409,6 +452,48 @@ def test_cpp_api_lazy_image(orc, torch_cuda, tmp_path, mode, flags, lanes):
         o.pathtrace(m, it, ref)
     assert ref.sum() > 0
     assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+    if not flags:
+        # control: with the automatic resolve switched off (PTK_LAZY_IMAGE=1) the same unedited loop saves the zeros pathtraceInit wrote —
+        # i.e. the equality above is the library's doing, not the driver's
+        env["PTK_LAZY_IMAGE"] = "1"
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert not np.fromfile(base + ".6samp.f32", np.float32).any()
+
+
+def test_reinit_with_tiles_in_flight_raw_abi(ptk, orc, torch_cuda):
+    """ptk_set_tiles_in_flight(K); init; free; init through the RAW C ABI (the Python Renderer re-sets every knob before each init and
+    hid this): the second init must succeed and render the same image; setting tiles back to 1 must give ONE lane, not K iterations in flight."""
+    lib = ptk.lib
+    s = ptk.Scene(os.path.join(SC, "cornell.txt"), res=(96, 80), depth=4).upload()
+    o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(96, 80), depth=4)
+    ref = np.zeros((o.P, 3), np.float32)
+    for it in (1, 2, 3):
+        o.pathtrace(orc.MODE_BSDF, it, ref)
+    lib.ptk_pathtrace_free()
+    assert lib.ptk_set_iterations_in_flight(1) == 0 and lib.ptk_set_graph_replay(1) == 0 and lib.ptk_set_sample_mode(ptk.MODE_BSDF) == 0
+    assert lib.ptk_set_tiles_in_flight(3) == 0
+    try:
+        for _ in range(3):                                      # init / free / init / free / init
+            assert lib.ptk_pathtrace_init(s.handle) == 0
+            for it in (1, 2, 3):
+                assert lib.ptk_pathtrace(None, 0, it) == 0
+            out = np.zeros((o.P, 3), np.float32)
+            assert lib.ptk_get_image(out.ctypes.data) == 0
+            assert np.array_equal(out, ref)
+            assert lib.ptk_pathtrace_free() == 0
+        assert lib.ptk_set_tiles_in_flight(1) == 0
+        assert lib.ptk_pathtrace_init(s.handle) == 0
+        # one lane again: iterations 1, 2, 3 land in ONE plane in order; with K lanes left over, ptk_get_live_counts would describe lane (3-1) % K
+        for it in (1, 2, 3):
+            assert lib.ptk_pathtrace(None, 0, it) == 0
+        out = np.zeros((o.P, 3), np.float32)
+        assert lib.ptk_get_image(out.ctypes.data) == 0 and np.array_equal(out, ref)
+        assert lib.ptk_set_iterations_in_flight(2) == ptk.E_BADARG      # (live context: knobs are refused)
+    finally:
+        lib.ptk_pathtrace_free()
+        lib.ptk_set_tiles_in_flight(1); lib.ptk_set_graph_replay(0); lib.ptk_set_iterations_in_flight(1)
+    s.close()
 
 
 def test_large_mesh_uploads_one_threaded_copy(ptk, torch_cuda):

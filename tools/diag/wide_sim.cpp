@@ -13,6 +13,10 @@ static int mtbvh_dir(const float* d) {
     return k + (d[k] > 0 ? 0 : 3);
 }
 
+// optional per-node visit histogram (wide_tree_stats.py: which share of the node visits the first N nodes of the breadth-first array take)
+static unsigned long long* g_hist = nullptr;
+extern "C" void wide_sim_set_hist(unsigned long long* h) { g_hist = h; }
+
 extern "C" void wide_sim(const uint32_t* nodes, int n_nodes, const float* leaves, int n_rays, const float* o, const float* d,
                          const float* tmin_init, int* node_visits, int* leaf_visits, float* t_out) {
     (void)n_nodes;
@@ -25,6 +29,7 @@ extern "C" void wide_sim(const uint32_t* nodes, int n_nodes, const float* leaves
         for (;;) {
             if (!(cur & 0x80000000u)) {
                 ++nv;
+                if (g_hist) ++g_hist[cur];
                 const uint32_t* nd = nodes + 36 * (size_t)cur;
                 float p[3]; std::memcpy(p, nd, 12);
                 double sc[3];

@@ -1,0 +1,115 @@
+"""CPU model (no GPU): structure of the 8-wide collapsed tree and what a walk over it costs per listed ray.
+
+Prints, for one mesh scene: node count, leaves, levels, mean children per node (fill), stack bound, and — with the rays of every bounce of one
+iteration taken from the oracle (the work list k_list builds) walked by tools/diag/wide_sim.cpp — node visits, leaf visits and loop trips per
+listed ray (mean / 99th percentile / slowest), and the wave cost sum(max over 32 consecutive rays).  Run once per collapse:
+    PTK_WIDE_COLLAPSE=greedy python tools/diag/wide_tree_stats.py bunny_cornell.txt 400
+    python tools/diag/wide_tree_stats.py bunny_cornell.txt 400
+usage: wide_tree_stats.py [scene] [res] [iteration]"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as orc                                    # noqa: E402
+ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
+
+so = "/tmp/libwidesim.so"
+subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "diag", "wide_sim.cpp")])
+W = C.CDLL(so)
+W.wide_sim.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+scn = sys.argv[1] if len(sys.argv) > 1 else "bunny_cornell.txt"
+res = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+it = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+path = os.path.join(ROOT, "scenes", scn)
+orc.set_trig_mode(orc.TRIG_PTK); orc.set_threads(8)
+S = orc.Scene(path, res=(res, res))
+ps = ptk.Scene(path, res=(res, res))
+nodes, leaves, depth, stack = ps.wide_bvh()
+leaves_f = np.ascontiguousarray(leaves).view(np.float32).reshape(-1, 16)
+nch = (nodes[:, 3] >> 24).astype(np.int64)
+refs = nodes[:, 7::4][:, :8]
+is_leaf = (refs & 0x80000000) != 0
+valid_slot = np.arange(8)[None, :] < nch[:, None]
+n_leaf_slots = int((is_leaf & valid_slot).sum())
+all_leaf = ((is_leaf | ~valid_slot).all(axis=1)).sum()
+print(f"{scn}: collapse={os.environ.get('PTK_WIDE_COLLAPSE', 'dp')}  {len(nodes)} nodes, {len(leaves)} leaves, {depth} levels, "
+      f"fill {nch.mean():.2f} / 8, all-leaf nodes {int(all_leaf)}, stack bound {stack}, histogram of children {np.bincount(nch, minlength=9)[1:].tolist()}")
+assert n_leaf_slots == len(leaves)
+
+bv = S.bvh()
+lo, hi = bv[0]["pMin"].astype(np.float64), bv[0]["pMax"].astype(np.float64)
+hist = np.zeros(len(nodes), np.uint64)
+W.wide_sim_set_hist.argtypes = [C.c_void_p]
+W.wide_sim_set_hist(hist.ctypes.data)
+paths = S.generate_rays(it)
+img = np.zeros((S.P, 3), np.float32)
+NV, NL = [], []
+for d in range(S.trace_depth):
+    isects, valid = S.intersect(paths)
+    o = paths["o"].astype(np.float64); dd = paths["d"].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / dd
+        t0 = (lo - o) * inv; t1 = (hi - o) * inv
+    tn = np.minimum(t0, t1).max(axis=1); tf = np.maximum(t0, t1).min(axis=1)
+    t_an = np.where((isects["triangleID"] < 0) & (isects["t"] > 0), isects["t"], np.float32(3.0e38)).astype(np.float32)
+    heavy = (tn <= tf) & (tf > 0) & ~(tn > t_an)
+    hi_idx = np.nonzero(heavy)[0]
+    n = len(hi_idx)
+    ro = np.ascontiguousarray(paths["o"][hi_idx]); rd = np.ascontiguousarray(paths["d"][hi_idx]); ti = np.ascontiguousarray(t_an[hi_idx])
+    nv = np.zeros(n, np.int32); nl = np.zeros(n, np.int32); tt = np.zeros(n, np.float32)
+    W.wide_sim(nodes.ctypes.data, len(nodes), leaves_f.ctypes.data, n, ro.ctypes.data, rd.ctypes.data, ti.ctypes.data, nv.ctypes.data, nl.ctypes.data, tt.ctypes.data)
+    NV.append(nv); NL.append(nl)
+    valid_s = S.shade(orc.MODE_BSDF, it, d, isects, paths, img)
+    paths, _ = orc.compact(valid_s, paths)
+    if len(paths) == 0: break
+nv = np.concatenate(NV).astype(np.int64); nl = np.concatenate(NL).astype(np.int64); v = nv + nl
+
+
+def wave_cost(x, G):
+    pad = (-len(x)) % G
+    return np.concatenate([x, np.zeros(pad, x.dtype)]).reshape(-1, G).max(axis=1).sum()
+
+
+print(f"listed rays {len(v)} over {len(NV)} bounces: node visits {nv.mean():.2f} (p99 {np.percentile(nv, 99):.0f}, max {nv.max()}), "
+      f"leaf visits {nl.mean():.2f} (max {nl.max()}), loop trips {v.mean():.2f} (p99 {np.percentile(v, 99):.0f}, max {v.max()})")
+print(f"bytes fetched per listed ray: {(144 * nv + 64 * nl).mean():.0f}; wave cost (32 rays, slowest ray): {wave_cost(v, 32)} trips = "
+      f"{wave_cost(v, 32) * 32 / v.sum():.2f} x the lane work")
+cum = np.cumsum(hist.astype(np.float64)) / max(float(hist.sum()), 1.0)
+print("share of the node visits taken by the first N nodes of the breadth-first array: " +
+      ", ".join(f"{n}: {cum[min(n, len(cum)) - 1]:.3f}" for n in (1, 9, 16, 32, 64, 128, 256, 455, 512, 680, 1024, len(cum))))
+
+
+def pool_cost(v, G, chunk, waves, thr, refill_cost=0.3):
+    """wave-iterations of a block-pooled walk with refill: a block of `waves` waves x G ray slots drains a chunk of `chunk` consecutive list
+    entries; a wave refills ALL its idle slots when at least thr x G of them are idle (or all are) and the pool is not empty."""
+    total = 0.0
+    for b0 in range(0, len(v), chunk):
+        q = list(v[b0:b0 + chunk]); qi = 0
+        rem = []
+        for w in range(waves):
+            take = q[qi:qi + G]; qi += len(take); rem.append(np.array(take + [0] * (G - len(take)), np.int64))
+        for w in range(waves):
+            r = rem[w]
+            while True:
+                idle = int((r <= 0).sum())
+                if qi < len(q) and (idle >= thr * G or idle == G):
+                    k = np.nonzero(r <= 0)[0][:len(q) - qi]
+                    r[k] = q[qi:qi + len(k)]; qi += len(k); total += refill_cost
+                    continue
+                if idle == G: break
+                # (waves run one after the other in this model; they share the pool in list order, which is what a block counter does on average)
+                r -= 1; total += 1
+    return total
+
+
+base = wave_cost(v, 32)
+for chunk, thr in ((256, 0.25), (512, 0.25), (512, 0.5), (1024, 0.25), (1024, 0.125), (2048, 0.25)):
+    c = pool_cost(v, 32, chunk, 4, thr)
+    print(f"pooled walk, 32 slots per wave, 4 waves, chunk {chunk}, refill at {thr:.3f} idle: {c:.0f} wave-iterations = {c / base:.3f} x today's, {c * 32 / v.sum():.2f} x the lane work")
