@@ -390,8 +390,11 @@ def main():
                 h = red.cpu(); dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
 
         it = 0
+        tw0 = time.perf_counter()
         for _ in range(a.warmup * IPS):
             it += 1; r.iterate(it)
+        r.sync()
+        t_step_est = (time.perf_counter() - tw0) / max(a.warmup, 1)      # one step's time, from the warm-up (first-launch costs included: an upper bound)
         how = "reduce"
         t_red = t_gat = 0.0
         if N > 1:                      # warm the communicator outside the timed region, and time both collectives alone
@@ -404,10 +407,15 @@ def main():
                 tt = (time.perf_counter() - tt0) / 3
                 if kind == "reduce": t_red = tt
                 else: t_gat = tt
-            if own is not None and (a.collective == "gather" or (a.collective == "auto" and t_gat < t_red)):
-                how = "gather"             # (the 2 % rule is applied below, once the step time is known: here the cheaper one is simply pre-selected)
-            if a.collective == "reduce":
-                how = "reduce"
+            # every rank must call the SAME collective, so the choice is made here — before the timed region, from figures that are
+            # identical on every rank (MAX over ranks) — never from a rank-local clock inside it.  "auto": the full-frame reduce stays unless it is
+            # worth more than 2 % of a step (estimated from the warm-up) and the gather of the own tiles is cheaper
+            tl = torch.tensor([t_red, t_gat, t_step_est], dtype=torch.float64, device=cdev); dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            t_red, t_gat, t_step_est = float(tl[0]), float(tl[1]), float(tl[2])
+            if own is not None and a.collective == "gather":
+                how = "gather"
+            elif own is not None and a.collective == "auto" and t_red > 0.02 * t_step_est and t_gat < t_red:
+                how = "gather"
         barrier()
         rays0 = r.ray_total()
         barrier()
@@ -417,11 +425,7 @@ def main():
             it += 1; r.iterate(it)
         dev_ms = r.timer_stop()
         if N > 1:
-            # "auto": the full-frame reduce stays unless it is worth more than 2 % of the step it ends; every rank decides alike (MAX below)
-            if a.collective == "auto" and own is not None:
-                tl = torch.tensor([t_red, t_gat], dtype=torch.float64, device=cdev); dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-                how = "gather" if (float(tl[0]) > 0.02 * (time.perf_counter() - t0) / max(a.steps, 1) and float(tl[1]) < float(tl[0])) else "reduce"
-            reduce_radiance(how)
+            reduce_radiance(how)           # (the job's one collective; which one was settled before the clock started)
         barrier()
         elapsed = time.perf_counter() - t0
         rays = r.ray_total() - rays0

@@ -17,7 +17,17 @@
 // (the image copied after every call, pathtrace.cu:809-810), --in-flight / --tiles / --graph are the ptk_set_* knobs; without them pathtraceInit
 // chooses three iterations in flight + graph replay with ordered accumulation in every sample mode (image bit-identical to one at a time).
 // --reinit-at N: pathtraceFree() + pathtraceInit() again after iteration N and start over (what the viewer does on a camera / mode change).
+//
+// RCCL (round 5; north star: "independent pixel tiles shard across the GPUs of one node with an RCCL reduce of the accumulated radiance buffer over
+// xGMI").  One process per GPU: `ptk_headless SCENE --ranks N --rank R --id-file PATH [--tile-rows T]`.  Rank 0 writes the ncclUniqueId
+// to PATH (the launcher's only job is to start N processes with the same PATH), every rank joins the communicator (ncclCommInitRank), renders its
+// row tiles t = R (mod N) (ptk_set_tile_partition: no collective on the data path), and ONE ncclReduce(sum, float32, 3 * W * H) of the device
+// images — zero outside a rank's own tiles — puts the frame on rank 0, which saves it.  The clock (after a ncclAllReduce as the barrier) covers the
+// pathtrace() calls and the reduce; rank 0 prints the whole job's rays (ncclReduce of the ranks' ray counters) in the cpp_rccl line.  A rank count
+// above the visible GPUs is refused with one line and exit code 6: two ranks never share a device.
 #include "pathtrace.h"
+#include <rccl/rccl.h>
+#include <unistd.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -61,6 +71,32 @@ static bool writePNG(const std::string& path, int W, int H, const unsigned char*
     return true;
 }
 
+#define RCCL_CHECK(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { std::fprintf(stderr, "RCCL error (%s:%d): %s: %s\n", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); std::exit(EXIT_FAILURE); } } while (0)
+#define HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::fprintf(stderr, "HIP error (%s:%d): %s: %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); std::exit(EXIT_FAILURE); } } while (0)
+
+// the ncclUniqueId through a file: rank 0 writes PATH.tmp and renames it (atomic), the others wait for PATH (at most 120 s)
+static void exchange_id(ncclUniqueId& id, int rank, const std::string& path) {
+    if (rank == 0) {
+        RCCL_CHECK(ncclGetUniqueId(&id));
+        const std::string tmp = path + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) { std::fprintf(stderr, "ptk_headless: cannot write %s\n", tmp.c_str()); std::exit(7); }
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) { std::fprintf(stderr, "ptk_headless: cannot rename %s\n", tmp.c_str()); std::exit(7); }
+        return;
+    }
+    for (int tries = 0; tries < 2400; ++tries) {
+        if (FILE* f = std::fopen(path.c_str(), "rb")) {
+            const size_t n = std::fread(&id, sizeof id, 1, f);
+            std::fclose(f);
+            if (n == 1) return;
+        }
+        usleep(50000);
+    }
+    std::fprintf(stderr, "ptk_headless: rank %d: no ncclUniqueId in %s after 120 s\n", rank, path.c_str());
+    std::exit(7);
+}
+
 static float aces(float x) {        // utilities.h:35-43
     const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
     float y = (x * (a * x + b)) / (x * (c * x + d) + e);
@@ -101,6 +137,8 @@ static void saveImage(const Scene& scene, int iteration, const std::string& base
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("Usage: %s SCENEFILE.txt [--mode bsdf|direct|mis] [--iters N] [--res W H] [--depth D] [--out BASE]\n", argv[0]); return 1; }
     int iters = -1, rw = -1, rh = -1, depth = -1, warmup = 0, in_flight = 0, graph = -1, tiles = 0, reinit_at = 0;
+    int ranks = 1, rank = 0, tile_rows = 8;
+    std::string id_file;
     bool save = true, eager = false;
     std::string out;
     for (int i = 2; i < argc; ++i) {
@@ -117,12 +155,40 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--no-save")) save = false;
         else if (!std::strcmp(argv[i], "--eager")) eager = true;
         else if (!std::strcmp(argv[i], "--reinit-at") && i + 1 < argc) reinit_at = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--rank") && i + 1 < argc) rank = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--id-file") && i + 1 < argc) id_file = argv[++i];
+        else if (!std::strcmp(argv[i], "--tile-rows") && i + 1 < argc) tile_rows = std::atoi(argv[++i]);
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::printf("No HIP-capable devices were detected.\n"); return 2; }
+    const bool multi = !id_file.empty() || ranks > 1;
+    if (multi) {
+        if (ranks < 1 || rank < 0 || rank >= ranks || tile_rows < 1 || id_file.empty()) { std::printf("usage: --ranks N --rank R (0 <= R < N) --id-file PATH [--tile-rows T]\n"); return 5; }
+        if (ranks > ndev) { std::printf("ptk_headless: %d ranks need %d GPUs, %d visible (one process per GPU; two ranks never share a device)\n", ranks, ranks, ndev); return 6; }
+        HIP_CHECK(hipSetDevice(rank));
+    }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, 0) == hipSuccess)
-        std::printf("Device 0: \"%s\" %s, %d CUs, core clock %d MHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+    if (hipGetDeviceProperties(&prop, multi ? rank : 0) == hipSuccess)
+        std::printf("Device %d: \"%s\" %s, %d CUs, core clock %d MHz\n", multi ? rank : 0, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+    ncclComm_t comm = nullptr;
+    hipStream_t cst = nullptr;
+    float* sync_word = nullptr;
+    if (multi) {
+        ncclUniqueId id;
+        exchange_id(id, rank, id_file);
+        RCCL_CHECK(ncclCommInitRank(&comm, ranks, id, rank));
+        HIP_CHECK(hipStreamCreateWithFlags(&cst, hipStreamNonBlocking));
+        HIP_CHECK(hipMalloc((void**)&sync_word, sizeof(float)));
+        HIP_CHECK(hipMemset(sync_word, 0, sizeof(float)));
+        if (ptk_set_tile_partition(ranks, rank, tile_rows)) { std::printf("bad tile partition\n"); return 5; }
+    }
+    auto barrier = [&]() {          // every rank's GPU work so far is done, and every rank is here
+        if (!multi) return;
+        ptk_stream_sync();
+        RCCL_CHECK(ncclAllReduce(sync_word, sync_word, 1, ncclFloat, ncclSum, comm, cst));
+        HIP_CHECK(hipStreamSynchronize(cst));
+    };
 
     Scene* scene = new Scene(argv[1], rw, rh, depth);
     if (!scene->ok) { std::printf("%s\n", scene->error.c_str()); return 3; }
@@ -146,20 +212,55 @@ int main(int argc, char** argv) {
         if (iteration == 0) { pathtraceFree(); pathtraceInit(scene); }
         if (iteration < total) {
             iteration++; pathtrace(nullptr, 0, iteration);
-            if (iteration == warmup) { ptk_stream_sync(); ptk_get_ray_total(&rays0); t0 = std::chrono::steady_clock::now(); }
+            if (iteration == warmup) { ptk_stream_sync(); barrier(); ptk_get_ray_total(&rays0); t0 = std::chrono::steady_clock::now(); }
             if (iteration == reinit_at) { reinit_at = 0; iteration = 0; }      // the viewer's camchanged: runCuda() starts over (main.cpp:173-201)
         }
         else break;                                      // main.cpp:221-225: saveImage(); pathtraceFree(); exit
     }
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     unsigned long long rays = 0;
     ptk_get_ray_total(&rays);
+    double reduce_ms = 0.0;
+    if (multi) {
+        // ONE reduce of the radiance sums (each rank's image is zero outside its own tiles): the frame lands on rank 0, straight from the render
+        // context's device image — no host staging
+        const size_t n = 3 * (size_t)scene->state.camera.resolution.x * scene->state.camera.resolution.y;
+        float* img_dev = nullptr; float* frame = nullptr;
+        if (ptk_get_image_device(&img_dev)) { std::printf("ptk_get_image_device failed\n"); return 8; }
+        if (rank == 0) HIP_CHECK(hipMalloc((void**)&frame, n * sizeof(float)));
+        unsigned long long* rays_dev = nullptr;
+        HIP_CHECK(hipMalloc((void**)&rays_dev, 2 * sizeof(unsigned long long)));
+        const unsigned long long mine = rays - rays0;
+        HIP_CHECK(hipMemcpy(rays_dev, &mine, sizeof mine, hipMemcpyHostToDevice));
+        const auto r0 = std::chrono::steady_clock::now();
+        RCCL_CHECK(ncclReduce(img_dev, frame, n, ncclFloat, ncclSum, 0, comm, cst));
+        RCCL_CHECK(ncclReduce(rays_dev, rays_dev + 1, 1, ncclUint64, ncclSum, 0, comm, cst));
+        HIP_CHECK(hipStreamSynchronize(cst));
+        reduce_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+        if (rank == 0) {
+            HIP_CHECK(hipMemcpy(scene->state.image.data(), frame, n * sizeof(float), hipMemcpyDeviceToHost));
+            unsigned long long all = 0;
+            HIP_CHECK(hipMemcpy(&all, rays_dev + 1, sizeof all, hipMemcpyDeviceToHost));
+            rays = rays0 + all;
+            HIP_CHECK(hipFree(frame));
+        }
+        HIP_CHECK(hipFree(rays_dev));
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const int timed = iteration - (warmup < iteration ? warmup : 0);
     std::printf("%d iterations in %.3f s (%.2f ms/iteration), TracedDepth %d\n", iteration, sec, 1e3 * sec / std::max(1, timed), guiData->TracedDepth);
     std::printf("cpp_api {\"iterations\": %d, \"warmup\": %d, \"seconds\": %.6f, \"rays\": %llu, \"eager\": %d, \"in_flight\": %d, \"graph\": %d}\n",
                 timed, warmup < iteration ? warmup : 0, sec, rays - rays0, eager ? 1 : 0, in_flight > 0 ? in_flight : 1, graph > 0 ? 1 : 0);
-    if (save) saveImage(*scene, iteration, out);
+    if (multi) std::printf("cpp_rccl {\"ranks\": %d, \"rank\": %d, \"tile_rows\": %d, \"iterations\": %d, \"seconds\": %.6f, \"rays\": %llu, \"reduce_ms\": %.4f}\n",
+                           ranks, rank, tile_rows, timed, sec, rays - rays0, reduce_ms);
+    if (save && rank == 0) saveImage(*scene, iteration, out);
     pathtraceFree();
+    if (multi) {
+        barrier();
+        HIP_CHECK(hipFree(sync_word));
+        RCCL_CHECK(ncclCommDestroy(comm));
+        HIP_CHECK(hipStreamDestroy(cst));
+        ptk_set_tile_partition(1, 0, 1);
+    }
     Resource::clear();
     scene->clear();
     delete scene;

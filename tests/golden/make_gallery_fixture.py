@@ -14,6 +14,7 @@ What goes in, per image:
 and once:
   slot_shift       int8    [21,1080]    see below
   slot_shift_deep  int8    [21,1080]    the same offset for depth >= 1 (fit_deep_shifts; fitted on MIS20.png)
+  slot_shift_deep_left int8 [21,1080]   the same fit with only columns 0..539 of MIS20.png voting (hold-out: tests score columns 540..1079)
   lit              bool    [304,1080]   plate pixels (Direct2000 sum of channels > 30) in rows 636..939
 
 **slot_shift: what it is and why it exists.**  The reference keys its shading RNG by the COMPACTED slot of a path
@@ -95,16 +96,20 @@ def fit_slot_shifts(orc, direct20, direct2000):
     return sm
 
 
-def fit_deep_shifts(orc, table, mis20_rows, lit_rows, kmin=-16, kmax=16):
+def fit_deep_shifts(orc, table, mis20_rows, lit_rows, kmin=-16, kmax=16, cols=None):
     """The compacted-slot offset of the reference's run at DEPTH >= 1 (round 4; tools/diag/mis20_residue.py found that the pixels of MIS20.png the
     depth-0 table does not reproduce are exactly those that carry a contribution keyed by a depth >= 1 slot — the survivors of bounce 0 are
     compacted again, and the reference's build flipped other hit / miss decisions there).  Fitted on MIS20.png (Direct20 has no second bounce):
     coordinate descent over the iterations — iteration `it` is re-rendered with every candidate k1 for depth >= 1 (depth 0 keeps `table`), the
     20-iteration sum is re-formed with that iteration replaced, and per 4-row band the k1 with the most bit-identical lit plate pixels wins;
-    ties (bands no depth >= 1 contribution reaches) keep the depth-0 offset.  BSDF20.png is NOT used: tests/test_gallery.py checks it out of sample."""
+    ties (bands no depth >= 1 contribution reaches) keep the depth-0 offset.  BSDF20.png is NOT used: tests/test_gallery.py checks it out of sample.
+    cols = (c0, c1): only the saved image's columns c0..c1-1 vote (round 5: the hold-out table `slot_shift_deep_left` is fitted on the left half and
+    MIS20 is scored on the right half, which shares the band's offset but none of the pixels — out-of-sample evidence for the MIS-only terms)."""
     orc.L.orc_set_debug_slot_shift_deep.argtypes = [orc.ci, orc.ci]
     ref = mis20_rows.astype(np.int32)
     lit = lit_rows & (ref.sum(axis=2) > 0)
+    if cols is not None:
+        lit = lit.copy(); lit[:, :cols[0]] = False; lit[:, cols[1]:] = False
     s = orc.Scene(SCENE)
 
     def render_it(it, k1_rows):
@@ -176,7 +181,12 @@ def main():
         g["slot_shift"] = np.load(OUT, allow_pickle=False)["slot_shift"]
     else:
         g["slot_shift"] = fit_slot_shifts(orc, imgs["Direct20"], imgs["Direct2000"])
-    g["slot_shift_deep"] = fit_deep_shifts(orc, g["slot_shift"].astype(np.int32), g["rows_MIS20"], g["lit"])
+    if "--keep-deep" in sys.argv and os.path.exists(OUT):
+        g["slot_shift_deep"] = np.load(OUT, allow_pickle=False)["slot_shift_deep"]
+    else:
+        g["slot_shift_deep"] = fit_deep_shifts(orc, g["slot_shift"].astype(np.int32), g["rows_MIS20"], g["lit"])
+    # hold-out: the same fit with only the LEFT half of the saved image (columns 0..539) voting
+    g["slot_shift_deep_left"] = fit_deep_shifts(orc, g["slot_shift"].astype(np.int32), g["rows_MIS20"], g["lit"], cols=(0, W // 2))
     np.savez_compressed(OUT, **g)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

@@ -2,7 +2,7 @@
 caller) — the product sources plus the ptk_debug_* entry points, which libptk.so does not export — and writes its result to an .npz.
     python hooks_child.py exact_math <out.npz> <seed>
     python hooks_child.py gallery <out.npz> <Direct|BSDF|MIS>      the 20 iterations of scenes/mis_test2.txt, iteration by iteration, with the fixture's
-                                                                slot offsets (depth 0: slot_shift, depth >= 1: slot_shift_deep), summed in iteration order"""
+                                                                slot offsets (depth 0: slot_shift, depth >= 1: slot_shift_deep, or the table named by a 4th argument), summed in iteration order"""
 import ctypes as C
 import importlib
 import os
@@ -30,7 +30,7 @@ def main():
         import test_gallery as tg
         name = sys.argv[3]
         g = tg._fixture()
-        t0, t1 = g["slot_shift"].astype(np.int32), g["slot_shift_deep"].astype(np.int32)
+        t0, t1 = g["slot_shift"].astype(np.int32), g[sys.argv[4] if len(sys.argv) > 4 else "slot_shift_deep"].astype(np.int32)
         W = tg.W
         s = ptk.Scene(tg.SCENE)
         assert (s.width, s.height, s.trace_depth) == (W, W, 8)

@@ -79,10 +79,13 @@ def _render_with_table(orc, mode, table, deep=None):
     return acc
 
 
-def _plate_match(out_u8, g, name):
+def _plate_match(out_u8, g, name, cols=None):
+    """cols = (c0, c1): score only the saved image's columns c0..c1-1 (the held-out half of MIS20)"""
     ref = g["rows_" + name].astype(np.int32)
     d = np.abs(out_u8[R0:R1].astype(np.int32) - ref).max(axis=2)
     lit = g["lit"] & (ref.sum(axis=2) > 0)
+    if cols is not None:
+        lit = lit.copy(); lit[:, :cols[0]] = False; lit[:, cols[1]:] = False
     return float((d[lit] == 0).mean()), float((d[lit] <= 1).mean()), int(lit.sum())
 
 
@@ -102,6 +105,21 @@ def test_oracle_reproduces_gallery_pixels(gallery_oracle, name, min_exact, min_w
     # whole image through 8x8 block means (includes the three lights and the black background)
     db = np.abs(block_means(out, 8) - g["blocks8_" + name + "20"])
     assert db.mean() < 0.05 and np.percentile(db, 99.9) < 4.0, (db.mean(), db.max())
+
+
+def test_mis20_held_out_half(gallery_oracle):
+    """VERDICT r4 #6 — out-of-sample evidence for the MIS-only code (power heuristic, next-event add; pathtrace.cu:545-572).  `slot_shift_deep` is
+    fitted on MIS20 itself, so MIS20's 99.0 % is in-sample.  `slot_shift_deep_left` is the same fit with ONLY the saved image's columns 0..539
+    voting (tests/golden/make_gallery_fixture.py: the offset is one integer per iteration and 4-row band, i.e. 6 080 integers against 164 160
+    pixel values in a half); MIS20 is scored here on columns 540..1079, none of whose pixels the fit has seen.  Measured: printed below."""
+    orc = gallery_oracle
+    g = _fixture()
+    acc = _render_with_table(orc, MODES["MIS"], g["slot_shift"].astype(np.int32), g["slot_shift_deep_left"].astype(np.int32))
+    out = save_transform(acc, 20)
+    fit = _plate_match(out, g, "MIS20", cols=(0, W // 2))
+    held = _plate_match(out, g, "MIS20", cols=(W // 2, W))
+    print(f"MIS20, depth >= 1 offsets fitted on the left half: fitted half exact {fit[0]:.4f} ({fit[2]} px); HELD-OUT half exact {held[0]:.4f}, within 1 level {held[1]:.4f} ({held[2]} px)")
+    assert held[2] > 80000 and held[0] >= 0.98 and held[1] >= 0.992, held
 
 
 def test_mis20_residue_is_the_depth1_slot_offset(gallery_oracle):
@@ -242,3 +260,12 @@ def test_gpu_reproduces_gallery_pixels(tmp_path, name, min_exact, min_within1):
     exact, within1, n = _plate_match(out, g, name + "20")
     print(f"HIP path vs gallery/{name}20.png: {n} lit plate pixels, exact {exact:.4f}, within 1 level {within1:.4f}")
     assert exact >= min_exact and within1 >= min_within1, (exact, within1)
+    if name == "MIS":
+        # out of sample (test_mis20_held_out_half): depth >= 1 offsets fitted on the LEFT half of MIS20 only, the HIP path scored on the right half
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hooks_child.py"), "gallery", out_npz, name, "slot_shift_deep_left"],
+                           env=dict(os.environ, PTK_FLAVOUR="hooks"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = save_transform(np.load(out_npz, allow_pickle=False)["acc"], 20)
+        held = _plate_match(out, g, "MIS20", cols=(W // 2, W))
+        print(f"HIP path vs gallery/MIS20.png, HELD-OUT right half (offsets fitted on the left half): {held[2]} px, exact {held[0]:.4f}, within 1 level {held[1]:.4f}")
+        assert held[0] >= 0.975 and held[1] >= 0.99, held

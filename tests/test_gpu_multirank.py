@@ -208,3 +208,39 @@ def test_five_rank_rehearsal_at_configs4_rank_size(tmp_path, ptk):
     mine = r.image(); r.close()
     px = ptk.partition_pixels(res[0], res[1], world, 3, rows).ravel()
     assert np.array_equal(mine[px], red[px]) and mine[px].sum() > 0
+
+
+def test_cpp_rccl_driver_one_rank(tmp_path, orc):
+    """the C++ multi-GPU host path (csrc/main.cpp: ptk_headless --ranks N --rank R --id-file PATH): ncclGetUniqueId through a file,
+    ncclCommInitRank, ptk_set_tile_partition, an ncclAllReduce as the barrier, ONE ncclReduce(sum, float32, 3 W H) of the device images and one of
+    the ray counters.  On the one-GPU box N = 1: the communicator is created and both collectives EXECUTE (the first RCCL calls this code base
+    ever made), and the frame rank 0 saves == the single-process image == the oracle, bit for bit.  A rank count above the visible GPUs is
+    refused with one line (two ranks never share a device; RCCL itself rejects that)."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
+    base = str(tmp_path / "rccl")
+    W, H, D, N_IT = 120, 96, 5, 5
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PTK_")}
+    cmd = [exe, os.path.join(ROOT, "scenes", "cornell.txt"), "--mode", "bsdf", "--iters", str(N_IT), "--res", str(W), str(H), "--depth", str(D), "--out", base,
+           "--ranks", "1", "--rank", "0", "--id-file", str(tmp_path / "nccl_id"), "--tile-rows", "8", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("cpp_rccl ")]
+    assert len(line) == 1, r.stdout
+    rec = json.loads(line[0][len("cpp_rccl "):])
+    assert rec["ranks"] == 1 and rec["rank"] == 0 and rec["iterations"] == N_IT - 1 and rec["reduce_ms"] > 0
+    img = np.fromfile(base + f".{N_IT}samp.f32", np.float32).reshape(-1, 3)
+    orc.set_trig_mode(orc.TRIG_PTK)
+    o = orc.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(W, H), depth=D)
+    ref = np.zeros((o.P, 3), np.float32); rays = 0
+    for it in range(1, N_IT + 1):
+        n, _ = o.pathtrace(orc.MODE_BSDF, it, ref)
+        rays += n if it > 1 else 0                       # (the counter is read after the warm-up iteration)
+    assert ref.sum() > 0 and np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+    assert rec["rays"] == rays
+    # more ranks than GPUs: one line, exit code 6, nothing rendered
+    ndev = torch.cuda.device_count()
+    bad = subprocess.run([*cmd[:cmd.index("--ranks")], "--ranks", str(ndev + 1), "--rank", "0", "--id-file", str(tmp_path / "nccl_id2")],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode == 6 and f"{ndev + 1} ranks need {ndev + 1} GPUs, {ndev} visible" in bad.stdout, bad.stdout + bad.stderr

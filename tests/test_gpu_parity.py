@@ -513,6 +513,49 @@ def test_large_mesh_uploads_one_threaded_copy(ptk, torch_cuda):
     s.close(); t.close()
 
 
+def test_mesh_with_axis_parallel_edges_keeps_six_copies(ptk, orc, torch_cuda, tmp_path, monkeypatch):
+    """walking ONE direction copy with the rank tie rule equals the reference's direction-ordered walk only while no leaf is cut
+    (`tEnter > t_min`) in one order and tested in the other — which an fp32 inversion tEnter > t of a triangle's own box can do exactly where two
+    triangles tie: on a shared AXIS-PARALLEL edge (the edge lies in a face of both boxes).  A mesh with such edges therefore keeps six copies
+    however large it is: a tessellated box of 3 072 axis-aligned coplanar triangles (every face a 16 x 16 grid of quads split along the diagonal,
+    so the shared diagonals, grid lines and cube edges are hit exactly by the axis-parallel rays below) == the oracle through the 8-wide walk, its
+    threaded fallback and k_tail."""
+    n = 16
+    verts, faces = [], []
+    def vid(p):
+        verts.append(p); return len(verts)
+    for axis in range(3):
+        for side in (-0.5, 0.5):
+            grid = {}
+            for i in range(n + 1):
+                for j in range(n + 1):
+                    p = [0.0, 0.0, 0.0]; p[axis] = side; p[(axis + 1) % 3] = -0.5 + i / n; p[(axis + 2) % 3] = -0.5 + j / n
+                    grid[(i, j)] = vid(tuple(p))
+            for i in range(n):
+                for j in range(n):
+                    a_, b_, c_, d_ = grid[(i, j)], grid[(i + 1, j)], grid[(i + 1, j + 1)], grid[(i, j + 1)]
+                    faces += [(a_, b_, c_), (a_, c_, d_)]
+    (tmp_path / "gridcube.obj").write_text("".join(f"v {x} {y} {z}\n" for x, y, z in verts) + "".join(f"f {a_} {b_} {c_}\n" for a_, b_, c_ in faces))
+    text = open(os.path.join(SC, "bunny_cornell.txt")).read().replace("../scenes/model/bunny10k.obj", str(tmp_path / "gridcube.obj")).replace("SCALE       5 5 5", "SCALE       3 3 3")
+    path = str(tmp_path / "gridcube.txt"); open(path, "w").write(text)
+    monkeypatch.delenv("PTK_THREADED_COPIES", raising=False)
+    s = ptk.Scene(path, res=(120, 96), depth=8).upload()
+    assert s.n_triangles == 3072 and s.bvh_device_bytes()[0] == 6 * s.bvh_size * 32 and s.bvh_device_bytes()[3] == 0       # six copies, no rank table
+    o = orc.Scene(path, res=(120, 96), depth=8)
+    for mode in ("BSDF", "MIS"):
+        ref = np.zeros((o.P, 3), np.float32); lives = []
+        for it in (1, 2, 3):
+            lives.append(o.pathtrace(MODES[mode], it, ref)[1].copy())
+        for lanes in (1, 3):
+            r = ptk.Renderer(s, MODES[mode], in_flight=lanes, graph=lanes > 1)
+            got = []
+            for it in (1, 2, 3):
+                r.iterate(it); got.append(r.live_counts()[0].copy())
+            img = r.image(); r.close()
+            assert np.array_equal(np.stack(got), np.stack(lives)) and np.array_equal(img, ref), (mode, lanes)
+    s.close()
+
+
 @pytest.mark.parametrize("copies", [1, 6])
 def test_exact_ties_between_triangles(ptk, orc, torch_cuda, tmp_path, monkeypatch, copies):
     """A mesh whose every face is listed twice: EVERY triangle hit is an exact tie between two triangles, and the reference keeps the one its
