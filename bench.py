@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--collective", default="auto", choices=["auto", "reduce", "gather"],
                     help="N > 1, tile sharding: how the radiance reaches rank 0 — SUM-reduce of the full frame, or gather of the owned row tiles (1/N of the bytes); "
                          "auto = reduce unless it costs more than 2 %% of a step")
+    ap.add_argument("--cpp-rccl", type=int, default=1, help="1: also run the C++ / RCCL host path (csrc/ptk_headless --ranks N) as a child of every rank, after the headline")
     ap.add_argument("--lean", type=int, default=0, help="1: only the headline run and the roofline pass (no reference_order / cpu_baseline / BVH scene / contracted child)")
     return ap.parse_args()
 
@@ -144,6 +145,25 @@ def cpu_baseline(scene_path, res, depth, mode, seconds):
     return out
 
 
+def cpu_baseline_fixed(scene_path, res, depth, mode, iterations, threads):
+    """the oracle on a FIXED number of iterations of a workload (BASELINE.md's C1 / C3 definitions), `threads` OpenMP threads"""
+    import numpy as np
+    import oracle_lib as orc
+    orc.set_trig_mode(orc.TRIG_PTK)
+    o = orc.Scene(scene_path, res=res, depth=depth)
+    orc.set_threads(threads)
+    img = np.zeros((o.P, 3), np.float32)
+    rays = 0
+    t0 = time.perf_counter()
+    for it in range(1, iterations + 1):
+        r, _ = o.pathtrace(mode, it, img)
+        rays += r
+    el = time.perf_counter() - t0
+    orc.set_threads(1)
+    o.close()
+    return {"value": round(rays / el / 1e6, 4), "iterations": iterations, "rays": int(rays), "seconds": round(el, 2)}
+
+
 def measure_kernels(ptk, scene, mode, pipeline, steps):
     """Untimed diagnostic pass on ONE stream (no overlap): per-kernel device time from HIP events on the render stream, plus
     BVH traversal statistics for scenes with triangles."""
@@ -170,7 +190,7 @@ def measure_kernels(ptk, scene, mode, pipeline, steps):
     return prof, rays, counts, nodes, tris, rays_s
 
 
-ROUND = "r4" if os.path.exists(os.path.join(ROOT, "profiles", "r4_pmc.json")) else "r3"      # the committed profile set the line cites
+ROUND = next((r for r in ("r5", "r4", "r3") if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc.json" % r))), "r3")      # the committed profile set the line cites
 PMC_FILE = "profiles/%s_pmc.json" % ROUND
 PMC_TIMED_FILE = "profiles/%s_pmc_timed.json" % ROUND
 BYTES_PER_PATH_BOUNCE = 224   # whole bounce (intersect 76 + 2 x 8 index-only compaction + shade 132) per path-bounce
@@ -268,13 +288,19 @@ def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
     rp = rocprof_avg_us(scene_file, "k_shade_trace<0, false, false") if (scene.width, scene.height) == (800, 800) else None
     pm = ((pmc_record(scene_file) or {}).get("k_shade_trace") or {}) if (scene.width, scene.height) == (800, 800) else {}
     alg_per_launch = rays_p * BYTES_PER_PATH_BOUNCE / launches
-    return {"bound": "valu", "bound_note": "priced against the HBM roofline as the contract asks; measured (DESIGN.md section 5): with three iterations in flight the "
-                                           "vector ALUs are ~1.0 busy by the counters, the HBM carries ~0.5 of its peak and the LDS pipe ~0.4 — a balanced kernel "
-                                           "whose exact arithmetic (IEEE divide / sqrt, no contraction) sets the instruction count",
-            "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic_bytes_per_launch"),
+    # the contract figure is the rocprofv3 one (the committed summary of the same single-stream command); the live HIP-event figure —
+    # which brackets every launch with two event records, ~3 us of dispatch / event latency per launch — stays beside it as frac_hip_events
+    frac_rp = alg_per_launch / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS if rp else None
+    bound, bound_note = bound_from_counters(pm.get("counters") or {}, pm.get("traffic_bytes_per_launch"), rp or avg_us)
+    return {"bound": bound, "bound_note": bound_note,
+            "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round((frac_rp * HBM_PEAK_GBS) if frac_rp else achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(frac_rp if frac_rp else achieved / HBM_PEAK_GBS, 5),
+            "frac_source": ("algorithmic bytes per launch / k_shade_trace's average duration in profiles/%s_%s_kernel_stats_inflight1_p0.csv (rocprofv3 --kernel-trace --stats of "
+                            "`bench.py --lean 1 --in-flight 1 --graph 0`)" % (ROUND, (scene_file or "").replace(".txt", ""))) if frac_rp else "HIP events of this run (no committed rocprofv3 summary for this workload)",
+            "frac_hip_events": round(achieved / HBM_PEAK_GBS, 5), "achieved_hip_events": round(achieved, 2),
+            "traffic": pm.get("traffic_bytes_per_launch"),
             "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_FILE,
-            "frac_rocprof": round(alg_per_launch / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp else None,
+            "frac_rocprof": round(frac_rp, 4) if frac_rp else None,
             # `frac` prices the launch at the reference's struct sizes (224 B per path-bounce); the compact streams move less.  The same launch
             # time against the HBM bytes the counters saw = what the HBM really carries
             "frac_measured": round(pm["traffic_bytes_per_launch"] / ((rp or avg_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if pm.get("traffic_bytes_per_launch") else None,
@@ -285,6 +311,29 @@ def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
             "counters": pm.get("counters"),
             "note": "HIP events on the render stream, %d untimed iterations on one stream (launches of the sparse tail excluded); per-kernel ms/iter: %s" % (
                 steps, {k: round(v[0] / steps, 4) for k, v in prof.items()})}
+
+
+def bound_from_counters(c, traffic, launch_us):
+    """`bound` and its note from the committed counters of the kernel (profiles/<round>_pmc.json), not from a fixed string: the
+    HBM share (PMC traffic / launch time / 8 TB/s), the vector-ALU share (SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES-derived SIMD cycles)) and the
+    wave-time split (issuing / waiting on data or a barrier / waiting to issue; with the round-5 pass, the LDS and vector-memory parts of the wait)."""
+    if not c:
+        return "latency", "no committed counters for this workload; alone on one stream the launch is bound by its fixed latency (DESIGN.md section 5)"
+    split = c.get("wave_time_split") or {}
+    hbm = traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS if (traffic and launch_us) else None
+    valu = c.get("valu_busy_frac_at_2p4GHz")
+    wait = split.get("waiting_on_data_or_barrier")
+    parts = []
+    if hbm is not None: parts.append("HBM carries %.2f of 8 TB/s (counters)" % hbm)
+    if valu is not None: parts.append("vector ALUs busy %.2f of the launch at 2.4 GHz" % valu)
+    if split: parts.append("a wave's lifetime: issuing %.2f, waiting on data or a barrier %.2f, waiting to issue %.2f" % (split.get("issuing", 0), wait or 0, split.get("waiting_to_issue", 0)))
+    ws = c.get("wait_split")
+    if ws: parts.append("of the wait: LDS-instruction-attributed %.2f, vector-memory in flight %.2f, the rest (barriers, scalar loads) %.2f" % (ws.get("lds", 0), ws.get("vmem", 0), ws.get("other", 0)))
+    if hbm is not None and hbm >= 0.6: b = "hbm"
+    elif valu is not None and valu >= 0.6: b = "valu"
+    else: b = "latency"
+    return b, ("priced against the HBM roofline as the contract asks; by the committed counters (%s, one launch alone on one stream): " % PMC_FILE) + "; ".join(parts) + \
+              (" — neither pipe is saturated: the launch is bound by stalls (dependent loads and block barriers) at this occupancy" if b == "latency" else "")
 
 
 def roofline_valu(scene_file, roof):
@@ -466,6 +515,32 @@ def main():
                  "note": "tiles (weak / strong): every rank traces N / 1 samples of its interleaved row tiles per launch (per-GPU work fixed / "
                          "whole-frame work fixed, per-rank launches shrink by N); iteration_sharded (weak / strong): K*IPS / K*IPS/N "
                          "whole-frame iterations per rank"}
+    # The C++ multi-GPU host path (csrc/main.cpp): one ptk_headless process per rank — ncclCommInitRank through an id file, the tile
+    # partition, the pathtrace() calls, ONE ncclReduce of the device images — as a child of every rank, after the headline (never inside its timed
+    # region).  Fixed work (1 sample of the own tiles per launch = tiles/strong).  Optional: a failure is recorded, never raised.
+    cpp_rccl = None
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer-1_amd", "csrc", "ptk_headless")
+    if a.cpp_rccl and not a.lean and os.path.exists(exe) and (N == 1 or a.backend == "nccl"):
+        import subprocess
+        idf = "/tmp/ptk_nccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), N)
+        try:
+            if N > 1: dist.barrier()
+            if rank == 0 and os.path.exists(idf): os.remove(idf)
+            if N > 1: dist.barrier()
+            c = subprocess.run([exe, scene_path, "--mode", a.mode, "--iters", str((a.warmup + a.steps) * IPS), "--warmup", str(a.warmup * IPS), "--no-save",
+                                "--ranks", str(N), "--rank", str(local if N > 1 else 0), "--id-file", idf, "--tile-rows", str(a.tile_rows)]
+                               + (["--res", str(res[0]), str(res[1])] if res else []) + (["--depth", str(a.depth)] if a.depth >= 0 else []),
+                               capture_output=True, text=True, timeout=300)
+            j = json.loads([l for l in c.stdout.splitlines() if l.startswith("cpp_rccl ")][-1][len("cpp_rccl "):])
+            cpp_rccl = {"value": round(j["rays"] / j["seconds"] / 1e6, 3), "unit": "Mrays/s", "ranks": j["ranks"], "reduce_ms": j["reduce_ms"], "iterations": j["iterations"],
+                        "config": "csrc/ptk_headless --ranks N --rank r --id-file F: C++ host, one process per GPU, RCCL (ncclCommInitRank, ncclAllReduce barrier, one "
+                                  "ncclReduce(sum, float32, 3*W*H) of the device images + one of the ray counters); interleaved row tiles, 1 sample per launch (fixed work); "
+                                  "the clock covers the pathtrace() calls and the reduce"}
+        except Exception as e:
+            cpp_rccl = {"error": str(e)[:200]}
+        if N > 1:
+            try: dist.barrier()
+            except Exception: pass
     if rank == 0:
         # what ptk_set_pipeline(0) picks (include/ptk.h, pathtrace.hip use_trace_pipeline): the fused launches for triangle-free scenes, for meshes
         # of up to 1 024 triangles (walked inside the kernel) and, on larger meshes, in MIS mode
@@ -553,7 +628,7 @@ def main():
                 return {"value": round(j["rays"] / j["seconds"] / 1e6, 3), "ms_per_iteration": round(1e3 * j["seconds"] / j["iterations"], 4)}
             try:
                 cpp_api = dict(headless(), unit="Mrays/s",
-                               config=("csrc/ptk_headless: pathtraceInit + %d x pathtrace(nullptr, 0, it) + pathtraceResolve(), API defaults (" % (a.steps * IPS))
+                               config=("csrc/ptk_headless = the reference's loop, unedited: pathtraceInit + %d x pathtrace(nullptr, 0, it), the last call makes state.image current; API defaults (" % (a.steps * IPS))
                                       + "3 iterations in flight + graph replay, ordered accumulation = the reference's running sum, bit-identical image)",
                                one_at_a_time=headless("--in-flight", "1", "--graph", "0"),
                                overlapped=headless("--in-flight", str(a.in_flight), "--graph", str(a.graph)),
@@ -562,8 +637,22 @@ def main():
             except Exception as e:
                 cpp_api = {"error": str(e)[:200]}
         cpu = None
+        cpu_c1 = cpu_bvh = None
         if N == 1 and not a.lean and a.cpu_seconds > 0:
             cpu = cpu_baseline(scene_path, res, a.depth, mode, a.cpu_seconds)
+            # BASELINE.md section 2, C1 = BASELINE.json configs[0]: cornell.txt 400x400 depth 4, 16 iterations, single thread, BSDF and MIS
+            c1 = {}
+            for mname, mval in (("bsdf", ptk.MODE_BSDF), ("mis", ptk.MODE_MIS)):
+                c1[mname] = cpu_baseline_fixed(os.path.join(ROOT, "scenes", "cornell.txt"), (400, 400), 4, mval, 16, 1)
+            cpu_c1 = dict(c1, unit="Mrays/s", cores=1, kind="port",
+                          workload="scenes/cornell.txt 400x400 depth 4, 16 iterations (BASELINE configs[0]), oracle/pt_oracle.cpp, 1 thread; MIS counts the same "
+                                   "paths x bounces (shadow rays not counted, SURVEY 8d)")
+            if a.bvh_scene:
+                # C3: the BVH scene on all host cores (and one iteration on a single thread)
+                cores = host_cores()
+                cpu_bvh = {"all_cores": dict(cpu_baseline_fixed(os.path.join(ROOT, "scenes", a.bvh_scene), None, -1, mode, 4, cores), cores=cores),
+                           "one_thread": dict(cpu_baseline_fixed(os.path.join(ROOT, "scenes", a.bvh_scene), None, -1, mode, 1, 1), cores=1),
+                           "unit": "Mrays/s", "kind": "port", "workload": f"scenes/{a.bvh_scene} as shipped in this repo (800x800 depth 8), SampleMode {a.mode.upper()}"}
         contracted = None
         # (never under a profiler: the child would inherit the preload, contend for the counters and land in the trace — ADVICE r3)
         profiled = any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -610,11 +699,16 @@ def main():
             "device_ms_per_step": round(dev_ms / a.steps, 4), "ms_per_iteration": round(1e3 * elapsed / (a.steps * IPS), 4),
             "overlap_note": (f"{a.in_flight} iterations in flight on {a.in_flight} streams: ms_per_step is smaller than the sum of the "
                              "per-kernel times of one iteration (roofline.note) because iterations overlap") if a.in_flight > 1 else None,
-            "reference_order": ref_order, "cpp_api": cpp_api,
-            "roofline": roofline, "cpu_baseline": cpu, "contracted": contracted, "flavour": ptk.FLAVOUR,
+            "reference_order": ref_order, "cpp_api": cpp_api, "cpp_rccl": cpp_rccl,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "cpu_baseline_bvh_scene": cpu_bvh, "contracted": contracted, "flavour": ptk.FLAVOUR,
         }
         if multi is not None:
             out["multi_gpu"] = multi
+            # north_star's ">= 6x at 8 GPUs on cornell.txt 800x800 depth 8" is a FIXED-WORK statement.  `value` is the headline the
+            # contract's "scaling" key describes (weak by default: per-GPU work fixed); the fixed-work figure of the same job sits beside it
+            out["strong_scaling"] = {"value": multi["strong"]["value"], "unit": "Mrays/s", "what": "tiles/strong: the whole frame's work fixed, every rank traces 1 sample of "
+                                     "its own row tiles per launch (launches shrink by N) — the curve north_star's '>= 6x at 8 GPUs' is about",
+                                     "headline_is": multi["headline"]}
         if N == 1:
             # utilisation from counters taken IN the timed configuration (tools/pmc_timed.sh: one rocprofv3 --pmc pass over `bench.py --lean 1`,
             # summed over every dispatch), no assumed clock: VALU-active quad-cycles x 4 / (SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) — a fraction of the cycles the

@@ -180,15 +180,19 @@ int DevScene::initiate(Scene& scene) {
     // walk only as long as no leaf is cut (`tEnter > t_min`, pathtrace.cu:253) in one order and tested in the other.  tEnter <= t holds for a
     // triangle's own box in exact arithmetic; in fp32 it can fail by an ulp where the hit point lies ON a face of the box — for a triangle with an
     // axis-parallel edge (two vertices sharing a coordinate: the edge lies in that face; a flat box is the extreme case) that is every hit on that
-    // edge, and a hit on a SHARED edge is also where two triangles tie or nearly tie.  Such meshes (tessellated boxes, architecture) keep six copies;
-    // for the others the remaining case is a ray through a vertex to the last bit that also nearly ties with another triangle.
-    bool axis_parallel_edge = false;
+    // edge, and a hit on a SHARED edge is also where two triangles tie or nearly tie.  Meshes made of such triangles (tessellated boxes,
+    // architecture) keep six copies.  A scanned mesh has a few by coincidence of its rounded coordinates (bunny10k: 4 of 10 000): it keeps one copy
+    // — the residue is a ray of the k_tail / fallback walks that crosses one of those edges to the last bit (~1e-7 of the rays that cross it) AND
+    // finds the two triangles within an ulp of each other.
+    int axis_parallel = 0;
     for (const Triangle& t : scene.triangles) {
-        for (int a = 0; a < 3 && !axis_parallel_edge; ++a)
-            for (int b = a + 1; b < 3; ++b)
-                if (t.v[a].x == t.v[b].x || t.v[a].y == t.v[b].y || t.v[a].z == t.v[b].z) { axis_parallel_edge = true; break; }
-        if (axis_parallel_edge) break;
+        bool hit = false;
+        for (int a = 0; a < 3 && !hit; ++a)
+            for (int b = a + 1; b < 3 && !hit; ++b)
+                hit = t.v[a].x == t.v[b].x || t.v[a].y == t.v[b].y || t.v[a].z == t.v[b].z;
+        axis_parallel += hit;
     }
+    const bool axis_parallel_edge = axis_parallel > std::max(8, tri_num / 1000);
     int copies = (wide_nodes > 0 && tri_num > 1024 && !axis_parallel_edge) ? 1 : 6;
     if (const char* e = getenv("PTK_THREADED_COPIES")) { const int c = atoi(e); if (c == 6 || (c == 1 && tri_num > 0)) copies = c; }
     if ((rc = upload_threaded(scene, copies))) return rc;
