@@ -129,7 +129,7 @@ int context_free() {
         dfree(l.ws.agg_h); dfree(l.ws.hit_pref); dfree(l.ws.tr_valid); dfree(l.ws.tr_heavy); dfree(l.ws.hcounts); dfree(l.ws.seg_first_h);
         dfree(l.ws.agg_a); dfree(l.ws.agg_b); dfree(l.ws.valid_a); dfree(l.ws.valid_b);
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
-        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev); dfree(l.cum);
+        dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev); dfree(l.cum); dfree(l.ws.look);
         for (hipEvent_t& e : l.ring_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
         if (l.graph) (void)hipGraphDestroy(l.graph);
@@ -160,9 +160,18 @@ int context_free() {
 // one iteration at a time, where the serial tail of that last block costs more than the launch: 0.352 vs 0.363 ms per iteration).
 // Pipeline 0 / 10: the fused k_shade_trace launches (one per bounce); they always do their own window bookkeeping.
 static bool trace_pipeline(int pipeline) { return pipeline == 0 || pipeline == 10; }
+// pipeline 11 (round 5): k_trace_shade — trace AND shade a bounce per launch, the hit record never leaves the block (ptk_kernels.hip).  Triangle-free
+// scenes without textures only; not with tiles in flight (the bands' cumulative hit counts ride on k_shade_trace), the per-kernel profiler's
+// intersect / shade split or the traversal counters.  PTK_TRACE_SHADE=0|1 overrides what pipeline 0 picks (A/B runs).
+static bool ts_pipeline_wanted(int pipeline) {
+    if (pipeline == 11) return true;
+    if (pipeline != 0) return false;
+    static const int forced = getenv("PTK_TRACE_SHADE") ? atoi(getenv("PTK_TRACE_SHADE")) : -1;
+    return forced == 1;
+}
 static bool fold_segments(int pipeline, int n_lanes) {
     if (pipeline == 7) return false;
-    if (pipeline == 8 || trace_pipeline(pipeline)) return true;
+    if (pipeline == 8 || pipeline == 11 || trace_pipeline(pipeline)) return true;
     return n_lanes > 1;
 }
 static int pick_lpr(int n_lanes) {
@@ -255,6 +264,10 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.srcidx, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.ws.seg_pref, blocks + 16))) return rc;
     if ((rc = dalloc(&l.ws.seg_first, blocks + 16))) return rc;
+    // pipeline 11's look-back tables: one tagged word per block (never cleared) + one accumulating word per group of 32 blocks behind them (zero here,
+    // cleared again by every launch's last block)
+    if ((rc = dalloc(&l.ws.look, 2 * blocks + 64))) return rc;
+    if ((e = hipMemsetAsync(l.ws.look, 0, sizeof(unsigned long long) * (2 * blocks + 64), l.stream)) != hipSuccess) return (int)e;
     const size_t n_done = 32 * ((size_t)blocks / 32 + 3);          // top counter + one per 32 blocks, each on its own 128-B line (segments_tail)
     if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
     if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
@@ -362,7 +375,11 @@ bool sparse_tail() { return g.pipeline != 1 && !g_prof.on &&
                             !(g.lanes.size() && g.lanes[0].ws.stats); }
 // the fused shade + trace launches: pipeline 10 always, pipeline 0 (auto) for triangle-free scenes — with a BVH stage behind every launch
 // the staged kernels are 1-3 % ahead (bunny scene 5.70 vs 5.62 Grays/s); the traversal counters are only kept by the staged kernels
+bool use_ts_pipeline() {
+    return ts_pipeline_wanted(g.pipeline) && !g.tiles && g.scene && trace_shade_usable(dev_view(*g.scene)) && !(g.lanes.size() && g.lanes[0].ws.stats);
+}
 bool use_trace_pipeline() {
+    if (use_ts_pipeline()) return false;
     if (!trace_pipeline(g.pipeline) || (g.lanes.size() && g.lanes[0].ws.stats)) return false;
     if (g.pipeline == 10 || g.tiles || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline)) return true;      // (tiny mesh: walked inside the fused kernel; tiles in flight: only the fused launches carry the bands' cumulative hit counts)
     // larger meshes: a BVH stage follows every launch either way.  The staged kernels are ahead in BSDF / DIRECT (bunny scene 5.93 vs 5.85, 7.8 vs
@@ -391,6 +408,22 @@ int enqueue_iteration(Lane& L, int iter, int mode, bool from_device_iter) {
         ws.cum_prev = li > 0 ? g.lanes[li - 1].cum : nullptr; ws.cum_out = L.cum; ws.cum_stride = g.traceDepth + 2; ws.ring_div = g.n_shards;
     }
     const int full = sparse_tail() ? std::min(std::max(L.full_bounces, 1), g.traceDepth) : g.traceDepth;
+    if (use_ts_pipeline()) {
+        // launch d traces and shades bounce d (launch 0 generates the camera rays); the survivors ping-pong between the two path buffers
+        void (*mark)(int, bool) = g_prof.on ? prof_mark : no_mark;
+        PtkPaths cur = L.bufA, nxt = L.bufB;
+        int rc = 0;
+        for (int d = 0; d < full && !rc; ++d) {
+            rc = launch_trace_shade(S, mode, cam, L.n_parts, L.part, L.tile_rows, L.n_pix, g.traceDepth, iter, d, L.capacity, cur, nxt, L.plane, ws, L.stream, d == g.traceDepth - 1, mark);
+            std::swap(cur, nxt);
+        }
+        if (!rc && full < g.traceDepth) {            // every remaining bounce in one single-workgroup launch (k_tail), as after the staged kernels
+            prof_mark(1, true);
+            rc = launch_tail(S, mode, iter, full, g.traceDepth, cur, nxt, L.plane, ws, L.stream);
+            prof_mark(1, false);
+        }
+        return rc;
+    }
     if (use_trace_pipeline()) {
         // launch 0 generates the camera rays and traces bounce 0; launch dt shades bounce dt - 1 and traces bounce dt (k_shade_trace)
         void (*mark)(int, bool) = g_prof.on ? prof_mark : no_mark;
@@ -821,7 +854,7 @@ int ptk_debug_clear_image(void) {
 }
 #endif
 int ptk_set_pipeline(int which) {
-    if (which < 0 || which > 10 || which == 2 || which == 3 || which == 4 || which == 9) return PTK_E_BADARG;      // retired A/B layouts: 3 (ticketed fusion, round 3); 2 (wave-uniform primitive loops), 4 (scatter-pass compaction), 9 (no k_tail) in round 4
+    if (which < 0 || which > 11 || which == 2 || which == 3 || which == 4 || which == 9) return PTK_E_BADARG;      // retired A/B layouts: 3 (ticketed fusion, round 3); 2 (wave-uniform primitive loops), 4 (scatter-pass compaction), 9 (no k_tail) in round 4
     if (g.live && g.tiles && !trace_pipeline(which)) return PTK_E_BADARG;
     if (g.live && which == 5) { const int rc = need_six_copies(); if (rc) return rc; }
     g.pipeline = which;

@@ -82,6 +82,7 @@ struct Workspace {               // per-render-context scratch, device memory
     // PTK_CUM_RING (the band above runs ahead); cum_prev = the band above's table (null for the first band), cum_out = this band's; null = off
     const int* cum_prev = nullptr; int* cum_out = nullptr; int cum_stride = 0, ring_div = 1;
     int wide_lpr = 4;            // lanes per ray of the wide walk (4 or 2; ptk_kernels.hip k_traverse_wide)
+    unsigned long long* look = nullptr;      // pipeline 11 (k_trace_shade): one look-back word per block of a launch [blocks + 1]
     int wide_pool = 0;           // > 0: the wide walk pools that many work-list rays per block (k_traverse_pool); 0: one ray per lane group (k_traverse_wide)
     int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)
     int capacity = 0;
@@ -100,6 +101,10 @@ struct TraceBufs { PtkPaths paths; PtkHits hits; int* hr; };
 int launch_shade_trace(const SceneView& S, int mode, bool gen, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int dt, int capacity, const TraceBufs& cur, const TraceBufs& nxt, float* img, const Workspace& ws, hipStream_t st,
                        bool last, void (*mark)(int, bool));
+// pipeline 11 (k_trace_shade): launch `depth` traces and shades bounce `depth` (0: camera rays) of `cur` into `nxt`
+bool trace_shade_usable(const SceneView& S);
+int launch_trace_shade(const SceneView& S, int mode, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
+                       int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img, const Workspace& ws, hipStream_t st, bool last, void (*mark)(int, bool));
 int launch_sum_planes(const float* planes, int n_planes, size_t plane_len, float* out, hipStream_t st);      // out = ((p0 + p1) + p2) + ...
 int launch_merge_planes(float* image, float* planes, unsigned char* flags, int n_planes, int n_pixels, hipStream_t st);      // image += the touched tiles of planes[0], planes[1], ... in order; planes = 0, flags = 0
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows);

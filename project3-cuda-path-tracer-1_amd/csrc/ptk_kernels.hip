@@ -1256,7 +1256,7 @@ __device__ __forceinline__ void segments_block(int n_prev, const int* __restrict
 // counters for the next launch.
 struct SegTail { int* done; int* pref; int* first; int* count_out; int* iter_advance; int iter_stride; };
 template <int NT>
-__device__ __forceinline__ void segments_tail(const SegTail& T, int n, int b, int total, int* __restrict__ agg_b) {
+__device__ __forceinline__ void segments_tail(const SegTail& T, int n, int b, int total, int* __restrict__ agg_b, unsigned long long* clear_words = nullptr, int n_clear = 0) {
     __shared__ int s_last;
     const int nb = (n + NT - 1) / NT, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
     if (threadIdx.x == 0) {
@@ -1272,6 +1272,7 @@ __device__ __forceinline__ void segments_tail(const SegTail& T, int n, int b, in
     __syncthreads();
     if (!s_last) return;
     for (int k = threadIdx.x; k <= ng; k += NT) __hip_atomic_store(T.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = threadIdx.x; k < n_clear; k += NT) __hip_atomic_store(clear_words + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (k_trace_shade's group words)
     segments_block<NT, true>(n, agg_b, T.pref, T.first, T.count_out, T.iter_advance, T.iter_stride);
 }
 
@@ -1933,6 +1934,266 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_trace_shade (round 5, pipeline 11) — TRACE bounce d and SHADE bounce d in one launch, for triangle-free scenes.
+//
+// k_shade_trace fuses the other way round (shade d-1, trace d) because the reference keys the shading RNG by the COMPACTED slot of a hit path
+// (pathtrace.cu:458,532): the rank of the hit among ALL hits of the bounce, which a block only knows when every earlier block has counted its
+// hits — a launch boundary gives that for free, and costs the hit record a round trip through HBM: 32 B written and 32 B read per path-bounce
+// of the 128 B the compact streams move, plus the inverse-map word and two dependent loads at the head of every block.  Here the record never
+// leaves the block: the block traces its 256 rays, counts its hits, publishes the count and obtains the number of hits in all earlier blocks by
+// a DECOUPLED LOOK-BACK (Merrill & Garland, "Single-pass parallel prefix scan with decoupled look-back", 2016): one 64-bit word per block,
+// {launch tag : 32 | status : 2 | value : 30}; status 1 = the block's own count, 2 = the inclusive prefix; wave 0 inspects 64 predecessors per
+// round and sums counts back to the first inclusive prefix.  A block only ever waits for blocks with a SMALLER index, which the dispatcher
+// started earlier (workgroups are dispatched in index order), so the wait cannot deadlock; the tag (iteration x 256 + bounce + 1, unique per
+// launch of a lane) makes stale words of earlier launches invisible without a clear.  (Rounds 1-2 tried the CHAINED form — every block waits for
+// its predecessor's prefix, pipeline 3 — and lost: 11 ns x 2 500 blocks in series.  Look-back has no chain: a block adds up counts that are
+// published before any prefix is.)
+//   streams: the reference's PathSegment as three 16-byte records (origin, pixel) (direction, bounces) (colour, prevPdf) — 48 B read + 48 B
+//   written per surviving path-bounce (k_shade_trace's compact layout: 64 + 64), in the staged pipeline's segmented windows (Gather), so that
+//   k_tail takes over unchanged; one launch per bounce, traceDepth per iteration (k_shade_trace: traceDepth + 1).
+//   phases: ray (camera ray or gathered path) -> LDS | closest hit, block-cooperative (analytic_closest_lds) | hit count, publish, look-back
+//   (wave 0) beside the counting sort by material type of the others | thread j shades the j-th hit of the sorted order: ray, winner key, hit
+//   point and deferred normal come from LDS where the trace phase left them, colour / prevPdf from HBM | [MIS / DIRECT: block-cooperative
+//   shadow phase] | survivor ranks, stores into the block's window, window bookkeeping by the last block (segments_tail).
+// Same paths, same keys, same order of additions into every pixel as every other pipeline: bit-identical images (tests/test_gpu_parity.py).
+// ------------------------------------------------------------------------------------------------------------------
+// (Measured and dropped, profiles/r5_ab_trace_shade.txt: a two-level form — one accumulating word per group of 32 blocks, every block sums the
+// complete groups before its own and its group's earlier blocks — removes the rounds but makes every waiting block poll the SAME few words:
+// 6.8 instead of 16.7 Grays/s.  The flat form's polls go to the block's own predecessors only.)
+// One round inspects PTK_LB_SPAN x 64 predecessors: every lane of wave 0 reads PTK_LB_SPAN words that are 64 blocks apart (loads issued together:
+// one round trip), so that the first blocks of a launch — nobody has an inclusive prefix yet, all reach the count at about the same time — need
+// 1 792 / 256 = 7 rounds at worst instead of 28.
+#ifndef PTK_LB_SPAN
+#define PTK_LB_SPAN 4
+#endif
+struct LookBack { unsigned long long* words; };       // [blocks + 1] per lane
+__device__ __forceinline__ unsigned long long lb_word(unsigned tag, unsigned status, unsigned value) { return ((unsigned long long)tag << 32) | ((unsigned long long)status << 30) | value; }
+// lane 0 of a wave of block b, as soon as the block's count is known (block 0: that is its inclusive prefix already)
+__device__ __forceinline__ void lookback_publish(const LookBack& lb, unsigned tag, int b, int count) {
+    __hip_atomic_store(lb.words + b, lb_word(tag, b == 0 ? 2u : 1u, (unsigned)count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave 0 of block b (b > 0 or not): the number of hits in blocks [0, b); publishes the block's inclusive prefix
+__device__ __forceinline__ int lookback_exclusive(const LookBack& lb, unsigned tag, int b, int count, int lane) {
+    if (b == 0) return 0;
+    int excl = 0;
+    for (int j = b - 1; ; ) {
+        unsigned long long w[PTK_LB_SPAN];
+        unsigned st[PTK_LB_SPAN];
+        int first_incl = 64 * PTK_LB_SPAN, first_missing = 64 * PTK_LB_SPAN;      // positions (distance from block j) over the whole span
+#pragma unroll
+        for (int k = 0; k < PTK_LB_SPAN; ++k) {
+            const int idx = j - 64 * k - lane;
+            w[k] = lb_word(tag, 2u, 0u);                             // (virtual blocks before block 0: inclusive prefix 0)
+            if (idx >= 0) w[k] = __hip_atomic_load(lb.words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = PTK_LB_SPAN - 1; k >= 0; --k) {
+            st[k] = ((unsigned)(w[k] >> 32) == tag) ? ((unsigned)w[k] >> 30) : 0u;
+            const unsigned long long incl = __ballot(st[k] == 2u), missing = __ballot(st[k] == 0u);
+            if (incl) first_incl = 64 * k + __builtin_ctzll(incl);
+            if (missing) first_missing = 64 * k + __builtin_ctzll(missing);
+        }
+        if (first_missing < first_incl) { __builtin_amdgcn_s_sleep(4); continue; }      // a predecessor this round needs has not published yet
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < PTK_LB_SPAN; ++k) v += (64 * k + lane <= first_incl) ? (int)((unsigned)w[k] & 0x3fffffffu) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        excl += v;
+        if (first_incl < 64 * PTK_LB_SPAN) break;
+        j -= 64 * PTK_LB_SPAN;
+    }
+    if (lane == 0) __hip_atomic_store(lb.words + b, lb_word(tag, 2u, (unsigned)(excl + count)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+#ifndef PTK_TS_WAVES_BSDF
+#define PTK_TS_WAVES_BSDF 7
+#endif
+#ifndef PTK_TS_WAVES_NEE
+#define PTK_TS_WAVES_NEE 6
+#endif
+template <int MODE, bool GEN>
+__global__ void __launch_bounds__(PTK_BLOCK, (MODE == PTK_MODE_BSDF ? PTK_TS_WAVES_BSDF : PTK_TS_WAVES_NEE))
+k_trace_shade(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n,
+              PtkPaths cur, Gather G, PtkPaths nxt, int* __restrict__ agg_s, LookBack lb, FilmArgs film, int spp, int slot_bias, SegTail tail,
+              int* __restrict__ count0, unsigned long long* __restrict__ ray_total) {
+    constexpr int NT = PTK_BLOCK, NW = NT / 64, NKEY = 6, MATS = 16, LP = 8;
+    constexpr int OVER = (MATS * (int)sizeof(DevMaterial) + 3 * NT * (int)sizeof(int)) > NT * LP * 2 ? (MATS * (int)sizeof(DevMaterial) + 3 * NT * (int)sizeof(int)) : NT * LP * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char s_over[OVER];      // trace phase: pair list; afterwards: materials + sort tables
+    __shared__ float4 s_stage[4 * NT];                                       // rays (8 KB), winners' hit points + deferred normals (6 KB), winner keys (2 KB)
+    float4* s_ray = s_stage;
+    float2* s_res = reinterpret_cast<float2*>(s_stage + 2 * NT);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_stage + 2 * NT + (3 * NT) / 2);
+    __shared__ int s_cnt[NW][NKEY];
+    __shared__ int s_red[NW];
+    __shared__ int s_tcnt[NW];
+    __shared__ unsigned long long s_alive[NT / 64];
+    constexpr bool NEE = MODE != PTK_MODE_BSDF;
+    __shared__ unsigned long long s_occ[NT / 64];
+    __shared__ int s_anyreq;
+    __shared__ int s_base;
+    DevMaterial* s_mats = reinterpret_cast<DevMaterial*>(s_over);
+    int* s_perm = reinterpret_cast<int*>(s_over + MATS * sizeof(DevMaterial));
+    int* s_hrank = s_perm + NT;
+    int* s_src = s_hrank + NT;
+    const TraceLds L = {s_ray, s_res, s_best, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
+
+    const int step = iter_ptr ? *iter_ptr : iter_arg;
+    const int n = GEN ? gen.n_pix * spp : (d_n ? *d_n : n_arg);      // rays of this bounce
+    const Film img = {film, depth};
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
+    if (b == 0 && tid == 0) {
+        if (GEN && count0) *count0 = n;
+        if (ray_total && n > 0) atomicAdd(ray_total, (unsigned long long)n);
+    }
+    if (b * NT >= n) {
+        if (n <= 0 && b == 0) segments_block<NT, false>(0, agg_s, tail.pref, tail.first, tail.count_out, tail.iter_advance, tail.iter_stride);
+        return;
+    }
+    const GeomStage gs = stage_geoms(S, false);          // published by the first barrier of the trace phase
+    if (tid < NT / 64) { s_alive[tid] = 0ull; if (NEE) { s_occ[tid] = 0ull; s_anyreq = 0; } }
+    const int i = b * NT + tid;
+    const bool active = i < n;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // ---- the ray of dense path i: generateRayFromCamera (pathtrace.cu:135-163), or the survivor the previous launch left in its window
+    int src_mine = i;
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+    int pixw = 0, bounces = 0;
+    if (GEN) {
+        if (active) {
+            const int n_pix = gen.n_pix;
+            const int sidx = i / n_pix, jp = i - sidx * n_pix;
+            const int iter = (step - 1) * spp + sidx + 1;
+            const int lr = jp / gen.cam.W, x = jp - lr * gen.cam.W;
+            const int y = ((lr / gen.tile_rows) * gen.n_parts + gen.part) * gen.tile_rows + (lr % gen.tile_rows);
+            Rng rng = make_rng(x, y, iter);                       // argument order of pathtrace.cu:148: (iter:=x, index:=y, depth:=iter)
+            const f2 r = sample2D(rng);
+            const float fx = static_cast<float>(static_cast<float>(x) + ((double)r.x - 0.5) - gen.cam.W * 0.5f);
+            const float fy = static_cast<float>(static_cast<float>(y) + ((double)r.y - 0.5) - gen.cam.H * 0.5f);
+            rd = normalize(gen.cam.view - gen.cam.right * gen.cam.plx * fx - gen.cam.up * gen.cam.ply * fy);
+            ro = gen.cam.pos;
+            pixw = (sidx << 24) | (x + y * gen.cam.W); bounces = gen.trace_depth;
+        }
+    } else {
+        const int nw_prev = (d_n[-1] + NT - 1) / NT;            // windows of the stream being read = ceil(paths the previous launch shaded / 256)
+        src_mine = gather_source(G, b, i, n, nw_prev);          // 0 for i >= n
+        if (active) {
+            const float4 o4 = ld4(cur.o_pix, src_mine), d4 = ld4(cur.d_bnc, src_mine);
+            ro = mk3(o4.x, o4.y, o4.z); pixw = __float_as_int(o4.w);
+            rd = mk3(d4.x, d4.y, d4.z); bounces = __float_as_int(d4.w);
+        }
+    }
+    s_ray[tid] = make_float4(ro.x, ro.y, ro.z, __int_as_float(pixw));
+    s_ray[NT + tid] = make_float4(rd.x, rd.y, rd.z, __int_as_float(bounces));
+    // ---- trace phase (computeIntersections, pathtrace.cu:169-346): the winner's key, hit point and deferred normal stay in LDS
+    Analytic a;
+    analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
+    const int flag = active && a.geom >= 0;
+    const unsigned long long hb = __ballot(flag != 0);
+    if (lane == 0) s_red[wid] = __popcll(hb);
+    // ---- the pair list is dead: materials -> LDS (ends with a barrier, which also publishes s_red)
+    const MatTable mt = stage_materials<NT, MATS>(S, s_mats);
+    int hits = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int c = s_red[w]; before += (w < wid) ? c : 0; hits += c; }
+    const int iter = (step - 1) * spp + 1;
+    // ---- this block's hit count -> the look-back tables (every wave fetches the prefix itself, as late as possible: just before shading)
+    const unsigned lb_tag = (unsigned)step * 256u + (unsigned)depth + 1u;
+    if (tid == 0) lookback_publish(lb, lb_tag, b, hits);          // as early as possible: later blocks wait for it
+    int key = NKEY - 1;
+    if (flag) key = fetch_material_type(S, mt, __float_as_int(gs.xf[(size_t)a.geom * PTK_XF_FLOATS + 34]));
+    unsigned long long bal[NKEY];
+#pragma unroll
+    for (int k = 0; k < NKEY; ++k) bal[k] = __ballot(key == k);
+    if (lane < NKEY) s_cnt[wid][lane] = __popcll(bal[lane]);
+    s_src[tid] = src_mine;
+    s_hrank[tid] = before + __popcll(hb & lt);              // rank among the block's hits, in stream order: + s_base = the reference's compacted slot
+    __syncthreads();
+    int rank = 0, n_active = 0;
+#pragma unroll
+    for (int k = 0; k < NKEY; ++k) {
+        int before_waves = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = s_cnt[w][k]; before_waves += (w < wid) ? c : 0; tot += c; }
+        if (k < NKEY - 1) n_active += tot;
+        if (key == k) rank += before_waves + __popcll(bal[k] & lt);
+        else if (key > k) rank += tot;
+    }
+    s_perm[rank] = tid;
+    if (wid == 0) {                            // wave 0: hits of all earlier blocks (the barrier below publishes s_base); the count went out before the sort
+#ifdef PTK_DIAG_NO_LOOKBACK                    // timing experiments only (wrong keys): what the launch costs without the wait for the earlier blocks' counts
+        const int e = b * 200;
+#else
+        const int e = lookback_exclusive(lb, lb_tag, b, hits, lane);
+#endif
+        if (lane == 0) s_base = e;
+    }
+    __syncthreads();
+    // ---- shading phase: thread j shades the j-th hit of the sorted order
+    int alive = 0, src = -1;
+    PathRegs p;
+    p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
+    Hit h;
+    h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
+    int slot = 0;
+    const bool shading = tid < n_active;
+    if (shading) {
+        src = s_perm[tid];
+        slot = s_hrank[src] + slot_bias;
+        const float4 o4 = s_ray[src], d4 = s_ray[NT + src];
+        const unsigned long long best = s_best[src];
+        const float2 r0 = s_res[3 * src], r1 = s_res[3 * src + 1], r2 = s_res[3 * src + 2];
+        Analytic w;
+        w.t_min = __uint_as_float((unsigned)(best >> 32)); w.geom = (int)(unsigned)best;
+        w.P = mk3(r0.x, r0.y, r1.x); w.NS = mk3(r1.y, r2.x, r2.y);
+        analytic_record_staged(gs.xf, w, h);
+        p.o = mk3(o4.x, o4.y, o4.z); p.pix = __float_as_int(o4.w);
+        p.d = mk3(d4.x, d4.y, d4.z); p.bounces = __float_as_int(d4.w);
+        if (GEN) { p.col = mk3(1.f, 1.f, 1.f); p.prevPdf = -1.f; }
+        else { const float4 c4 = ld4(cur.col_pdf, s_src[src]); p.col = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w; }
+    }
+    ShadowReq rq; rq.on = false; rq.slot = s_stage + 2 * NT + tid; rq.dstride = NT; rq.pix = p.pix; rq.contrib = mk3(0, 0, 0);
+    if (NEE) __syncthreads();                  // every shading thread has its inputs in registers: the upper half of s_stage may take the shadow rays
+    slot += s_base;                            // hits of all earlier blocks: the reference's compacted slot = that + the rank among the block's hits
+    if (shading) {
+        alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img, NEE ? &rq : nullptr);
+        if (NEE && rq.on) s_anyreq = 1;
+    }
+    // survivor rank in the ORIGINAL (dense) order — the next bounce's compacted order, hence its RNG keys
+    if (alive) atomicOr(&s_alive[src >> 6], 1ull << (src & 63));
+    __syncthreads();
+    int total = 0, my_rank = -1;
+    {
+        const unsigned long long m0 = s_alive[0], m1 = s_alive[1], m2 = s_alive[2], m3 = s_alive[3];
+        const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2);
+        total = c0 + c1 + c2 + __popcll(m3);
+        if (alive) {
+            const int w = src >> 6;
+            const unsigned long long mw = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
+            my_rank = (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0) + __popcll(mw & ((1ull << (src & 63)) - 1ull));
+        }
+    }
+    if (alive) {
+        const int s2 = b * NT + my_rank;
+        st4(nxt.o_pix, s2, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
+        st4(nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
+        st4(nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
+    }
+    if (NEE && s_anyreq) {                     // block-uniform (published by the barrier above)
+        // ---- shadow phase (LightSampler::occulusionTest, lightSample.h:59-139) for the block's next-event samples, block-cooperatively
+        const TraceLds Lsh = {s_stage + 2 * NT, nullptr, nullptr, reinterpret_cast<unsigned short*>(s_over + MATS * sizeof(DevMaterial)), s_tcnt};
+        f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0); int s_pix = 0;
+        if (rq.on) { const float4 o4 = rq.slot[0], d4 = rq.slot[NT]; so = mk3(o4.x, o4.y, o4.z); sd = mk3(d4.x, d4.y, d4.z); s_pix = __float_as_int(d4.w); }
+        analytic_anyhit_lds<NT, LP>(S, gs, Lsh, s_occ, rq.on, so, sd);
+        const bool occ = (s_occ[tid >> 6] >> (tid & 63)) & 1ull;
+        if (rq.on && !occ) add_radiance(img, s_pix, rq.contrib);
+    }
+    // publish the window's survivor count; the last block of the launch builds the window tables
+    segments_tail<NT>(tail, n, b, total, agg_s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // compact_rays, pathtrace.cu:614-631: k_count (per-block aggregates) + k_scatter (stable scatter, device count out)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PTK_BLOCK) k_count(int n_arg, const int* __restrict__ d_n, const int* __restrict__ valid, int* __restrict__ agg) {
@@ -2523,6 +2784,50 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
         if ((rc = launch_rc())) return rc;
     }
     return 0;
+}
+// pipeline 11 (k_trace_shade): launch `depth` traces AND shades bounce `depth` of the stream in `cur` (depth 0: generates the camera rays instead of
+// reading a stream) and leaves the survivors in `nxt`, window by window (the staged pipeline's stream format: k_tail follows unchanged).
+bool trace_shade_usable(const SceneView& S) { return S.n_tris == 0 && S.n_tex == 0 && S.env_tex < 0 && S.lds_geoms > 0; }
+template <int MODE, bool GEN>
+static int launch_trace_shade_t(const SceneView& S, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n, PtkPaths cur, const Gather& Ga,
+                                PtkPaths nxt, int* agg_s, LookBack lb, const FilmArgs& film, int spp, int slot_bias, const SegTail& tail, int* count0,
+                                unsigned long long* ray_total, hipStream_t st) {
+    k_trace_shade<MODE, GEN><<<grid_for(capacity), PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, cur, Ga, nxt, agg_s, lb, film, spp, slot_bias, tail, count0, ray_total);
+    return launch_rc();
+}
+int launch_trace_shade(const SceneView& S_in, int mode, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
+                       int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img, const Workspace& ws, hipStream_t st, bool last, void (*mark)(int, bool)) {
+    if (grid_for(capacity) == 0) return 0;
+    if (!ws.seg_pref || !ws.seg_first || !ws.agg_b || !ws.seg_done || !ws.look || !trace_shade_usable(S_in)) return PTK_E_BADARG;
+    SceneView S = S_in;
+    S.slim_hits = 1;
+    const bool gen = depth == 0;
+    GenArgs G;
+    G.cam.W = cam.resolution.x; G.cam.H = cam.resolution.y;
+    G.cam.pos = mk3(cam.position.x, cam.position.y, cam.position.z);
+    G.cam.view = mk3(cam.view.x, cam.view.y, cam.view.z);
+    G.cam.up = mk3(cam.up.x, cam.up.y, cam.up.z);
+    G.cam.right = mk3(cam.right.x, cam.right.y, cam.right.z);
+    G.cam.plx = cam.pixelLength.x; G.cam.ply = cam.pixelLength.y;
+    G.trace_depth = trace_depth; G.n_parts = std::max(1, n_parts); G.part = part; G.tile_rows = std::max(1, tile_rows); G.n_pix = n_pix; G.late_stores = 0;
+    const Gather Ga = {gen ? nullptr : ws.seg_pref, gen ? nullptr : ws.seg_first, nullptr};
+    const int* d_n = gen ? nullptr : ws.counts + depth;
+    const SegTail tail = {ws.seg_done, ws.seg_pref, ws.seg_first, ws.counts + depth + 1, last ? ws.iter_dev : nullptr, ws.iter_stride};
+    const int sbias = ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0);
+    const LookBack lb = {ws.look};
+    const int cap = gen ? n_pix * ws.spp : capacity;
+    mark(gen ? 0 : 2, true);
+    int rc;
+#define PTK_TS(M, GENF) launch_trace_shade_t<M, GENF>(S, G, iter, ws.iter_dev, depth, cap, d_n, cur, Ga, nxt, ws.agg_b, lb, film_of(img, ws), ws.spp, sbias, tail, ws.counts, ws.ray_total, st)
+    switch (mode) {
+    case PTK_MODE_BSDF: rc = gen ? PTK_TS(PTK_MODE_BSDF, true) : PTK_TS(PTK_MODE_BSDF, false); break;
+    case PTK_MODE_DIRECTLI: rc = gen ? PTK_TS(PTK_MODE_DIRECTLI, true) : PTK_TS(PTK_MODE_DIRECTLI, false); break;
+    case PTK_MODE_MIS: rc = gen ? PTK_TS(PTK_MODE_MIS, true) : PTK_TS(PTK_MODE_MIS, false); break;
+    default: rc = PTK_E_BADARG;
+    }
+#undef PTK_TS
+    mark(gen ? 0 : 2, false);
+    return rc;
 }
 // all bounces from `depth0` on in one single-workgroup launch (k_tail); cur = the stream entering bounce depth0
 int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace_depth, PtkPaths cur, PtkPaths nxt, float* img,

@@ -185,11 +185,12 @@ def test_pathtrace_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert ref.sum() > 0
 
 
-@pytest.mark.parametrize("pipeline", [1, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("pipeline", [1, 5, 6, 7, 8, 10, 11])
 def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
     """ptk_set_pipeline variants (1 = staged kernels with the BVH walked inside the intersect kernel, 5 = staged kernels with the work-list
     rays on the reference's threaded walk, 6 = on the 8-wide collapsed tree, 7 / 8 = staged kernels with the window bookkeeping in a separate
-    k_segments launch / in the shading kernel's last block, 10 = one fused shade + trace launch per bounce; 0 picks 10 or 8 by scene) produce
+    k_segments launch / in the shading kernel's last block, 10 = one fused shade + trace launch per bounce, 11 = one fused trace + shade launch
+    per bounce where the scene has no triangles, else as 8; 0 picks by scene) produce
     exactly the oracle's results; the layouts retired in rounds 3-4 (2, 3, 4, 9) are refused."""
     for gone in (2, 3, 4, 9):
         assert ptk.lib.ptk_set_pipeline(gone) == ptk.E_BADARG
@@ -206,6 +207,61 @@ def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
             assert np.array_equal(counts, live), (name, it)
         img = r.image(); r.close()
         assert np.array_equal(img, ref), name
+
+
+TS_CASES = [("cornell.txt", (200, 168), 8, "BSDF"), ("cornell.txt", (200, 168), 8, "MIS"), ("cornell.txt", (131, 77), 5, "DIRECT"),
+            ("mis_test.txt", (256, 256), 16, "MIS"), ("mis_test.txt", (256, 256), 16, "BSDF"), ("mis_test2.txt", (216, 216), 8, "DIRECT"),
+            ("metallic_analytic.txt", (160, 160), 8, "MIS"), ("metallic_analytic.txt", (160, 160), 8, "BSDF"), ("cornell.txt", (24, 24), 8, "BSDF")]
+
+
+@pytest.mark.parametrize("name,res,depth,mode", TS_CASES)
+def test_trace_shade_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
+    """Round 5, pipeline 11 — k_trace_shade: a launch TRACES and SHADES one bounce, the hit record never leaves the block, and the reference's RNG
+    key (the compacted slot of a hit path, pathtrace.cu:458,532) comes from a decoupled look-back over the blocks' hit counts inside the launch.
+    Radiance, per-bounce live counts and the ray total == the oracle, bit for bit: one iteration at a time and three in flight with graph replay
+    (ordered accumulation), closed and open scenes (mis_test: the sparse tail takes over), every sample mode, frames that are not a multiple of
+    the window size."""
+    m = MODES[mode]
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    ref = np.zeros((o.P, 3), np.float32); lives = []; rays = 0
+    for it in range(1, 8):
+        rr, live = o.pathtrace(m, it, ref); lives.append(live.copy()); rays += rr
+    for lanes in (1, 3):
+        s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+        r = ptk.Renderer(s, m, pipeline=11, in_flight=lanes, graph=lanes > 1)
+        for it in range(1, 8):
+            r.iterate(it)
+            counts, _ = r.live_counts()
+            assert np.array_equal(counts, lives[it - 1]), (lanes, it, counts, lives[it - 1])
+        img = r.image()
+        assert r.ray_total() == rays
+        r.close(); s.close()
+        bad = (img != ref).any(axis=1)
+        assert not bad.any(), f"lanes {lanes}: {int(bad.sum())} of {len(ref)} pixels differ; first {np.argwhere(bad)[:3].ravel()}"
+
+
+def test_trace_shade_pipeline_full_size_and_sharded(ptk, orc, torch_cuda):
+    """the same at BASELINE configs[1]'s size (2 500 blocks per launch: 40 rounds of look-back for the last block) against the default pipeline's
+    image — itself checked against the oracle at this size by test_benchmarked_configuration_full_size — and under the tile partition with
+    samples per launch (the multi-GPU weak-scaling launch shape) against the oracle's emulation of that job."""
+    out = {}
+    for pipeline in (0, 11):
+        s = ptk.Scene(os.path.join(SC, "cornell.txt"))
+        r = ptk.Renderer(s, MODES["BSDF"], pipeline=pipeline, in_flight=3, graph=True)
+        for it in range(1, 13):
+            r.iterate(it)
+        out[pipeline] = (r.image(), r.live_counts()[0].copy(), r.ray_total()); r.close(); s.close()
+    assert out[0][2] == out[11][2] and np.array_equal(out[0][1], out[11][1]) and np.array_equal(out[0][0], out[11][0])
+    W, H, D, SPP, LANES = 96, 80, 5, 2, 2
+    o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
+    for part in (0, 1):
+        acc = orc.Accumulator(o.P, LANES, SPP, MODES["MIS"])
+        s = ptk.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
+        r = ptk.Renderer(s, MODES["MIS"], partition=(2, part, 8), pipeline=11, in_flight=LANES, graph=True, spp=SPP)
+        for step in range(1, 6):
+            r.iterate(step); acc.batch(o, MODES["MIS"], step, partition=(2, part, 8))
+        img = r.image(); r.close(); s.close()
+        assert np.array_equal(img, acc.img), part
 
 
 @pytest.mark.parametrize("name,mode", [("bunny_cornell.txt", "BSDF"), ("bunny_cornell.txt", "MIS"), ("obj_test.txt", "MIS")])
