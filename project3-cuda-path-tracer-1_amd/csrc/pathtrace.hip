@@ -37,22 +37,23 @@ struct Lane {
     PtkHits hits = {nullptr, nullptr, nullptr}, hitsB = {nullptr, nullptr, nullptr};     // hitsB, hrA/hrB: fused pipeline (hit records ping-pong with the paths)
     int* hrA = nullptr; int* hrB = nullptr;
     Workspace ws;
-    float* plane = nullptr;             // float[spp][n_depth][3*P]: the radiance of the launch in flight on this lane, merged into the image when it is done (merge_lane); the image itself with one lane, one sample per launch or tiles in flight
+    float* plane = nullptr;             // float[spp][n_depth][3*P]: the radiance of the launch in flight on this lane, merged into the image when it is done (flush_merges); the image itself with one lane, one sample per launch or tiles in flight
     unsigned char* flags = nullptr;     // touched-tile flags of those planes (ordered accumulation), [spp][n_depth][ceil(P / 64)]
     int last_iter = 0;
     // hipGraph replay of one iteration (all launches of render_iteration): the iteration number lives on the device
     int* iter_dev = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_mode = -1;
+    // one captured graph per plane set (batched merges: a lane alternates between two sets of planes, and the film pointers are baked into the launches)
+    struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int mode = -1, full = -1, late = -1; } gs[2];
+    int cur_set = 0;                    // the plane set (and graph slot) the lane's next iteration renders into
+    float* plane_sets[2] = {nullptr, nullptr}; unsigned char* flag_sets[2] = {nullptr, nullptr};
+    hipEvent_t set_free[2] = {nullptr, nullptr};      // recorded behind the merge that folded (and zeroed) the set
+    bool set_busy[2] = {false, false};  // set_free[k] has been recorded: the next iteration into set k waits for it
     int expected_iter = 0;              // value *iter_dev will hold when the next replay starts
     int* h_counts = nullptr;            // pinned host copy of ws.counts of an earlier iteration (asynchronous read-back, never waited for)
     hipEvent_t counts_ev = nullptr;
     bool counts_pending = false;
-    int graph_full = -1;                // full-width bounces the captured graph contains
-    int graph_late = -1;                // the camera launch's store placement the captured graph contains (g.gen_late)
     int* seg_done_mem = nullptr;        // Workspace::seg_done points here unless pipeline 7 asks for the separate k_segments launch
-    hipEvent_t merged = nullptr;        // ordered accumulation: recorded after this lane's merge_lane
+    hipEvent_t merged = nullptr;        // ordered accumulation: recorded after a merge that ran on this lane's stream (flush_merges)
     bool wait_resolved = false;         // the next enqueue must wait for lane 0's asynchronous reader of the planes / the image (plane sum, tone map of the previous pbo)
     int fresh_hint = 0;                 // iterations enqueued on this lane since the hint was reset (read-backs every iteration at first)
     // what this lane renders: the whole frame / this rank's tiles (iterations in flight), or ONE band of rows (tiles in flight)
@@ -76,10 +77,14 @@ struct RenderContext {
     float* image = nullptr;             // float[3*P]: the running sum, in iteration order (== planes when there is one plane)
     bool sched_explicit = false;        // ptk_set_iterations_in_flight / _tiles_in_flight / _graph_replay was called: pathtraceInit keeps the caller's schedule
     int want_ordered = -1;              // ptk_set_ordered_accumulation: -1 / 1 ordered (default), 0 planes that accumulate
-    bool ordered = false;               // several planes AND ordered accumulation (merge_lane); false: the planes accumulate, resolve_image sums them
+    bool ordered = false;               // several planes AND ordered accumulation (flush_merges); false: the planes accumulate, resolve_image sums them
     int n_depth = 1;                    // planes per sample: traceDepth + 1 (one per bounce) with ordered accumulation initialised in MIS mode, else 1
     unsigned char* flags = nullptr;     // [L][spp][n_depth][ceil(P / 64)] (ordered accumulation), else null
     hipEvent_t last_merged = nullptr;   // ordered accumulation: the event of the latest merge (some lane's `merged`), nullptr before the first
+    // batched merges (round 5): the iterations of up to `merge_batch` consecutive calls — consecutive lanes, the same plane set — are folded into
+    // the image by ONE k_merge_planes launch, in call order; a lane alternates between n_sets = 2 sets of planes so that it never waits for a merge
+    int merge_batch = 1, n_sets = 1;
+    int pend_first = 0, pend_n = 0, pend_set = 0;      // lanes pend_first .. pend_first + pend_n - 1 hold unmerged iterations in set pend_set
     unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
     int n_parts = 1, part = 0, tile_rows = 1;
@@ -131,8 +136,8 @@ int context_free() {
         dfree(l.ws.srcidx); dfree(l.ws.seg_pref); dfree(l.ws.seg_first); dfree(l.seg_done_mem); l.ws.seg_done = nullptr;
         dfree(l.ws.counts); dfree(l.ws.stats); dfree(l.ws.queue); dfree(l.ws.list); dfree(l.iter_dev); dfree(l.cum); dfree(l.ws.look);
         for (hipEvent_t& e : l.ring_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        if (l.graph_exec) (void)hipGraphExecDestroy(l.graph_exec);
-        if (l.graph) (void)hipGraphDestroy(l.graph);
+        for (Lane::GraphSlot& q : l.gs) { if (q.exec) (void)hipGraphExecDestroy(q.exec); if (q.graph) (void)hipGraphDestroy(q.graph); }
+        for (hipEvent_t& e : l.set_free) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (l.done) (void)hipEventDestroy(l.done);
         if (l.counts_ev) (void)hipEventDestroy(l.counts_ev);
         if (l.merged) (void)hipEventDestroy(l.merged);
@@ -147,7 +152,7 @@ int context_free() {
     if (g.ev0) { (void)hipEventDestroy(g.ev0); g.ev0 = nullptr; }
     if (g.ev1) { (void)hipEventDestroy(g.ev1); g.ev1 = nullptr; }
     if (g.resolved) { (void)hipEventDestroy(g.resolved); g.resolved = nullptr; }
-    g.last_merged = nullptr; g.ordered = false; g.n_depth = 1;
+    g.last_merged = nullptr; g.ordered = false; g.n_depth = 1; g.merge_batch = 1; g.n_sets = 1; g.pend_n = 0;
     g.live = false; g.tiles = false; g.n_lanes = g.want_lanes; g.scene = nullptr; g.P = g.capacity = 0;
     return 0;
 }
@@ -219,8 +224,13 @@ int lane_init(Lane& l, int idx) {
         for (hipEvent_t& ev : l.ring_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
     } else {
         l.n_parts = g.n_parts; l.part = g.part; l.tile_rows = g.tile_rows;
-        l.plane = g.planes + (size_t)idx * g.spp * g.n_depth * 3 * (size_t)g.P;
-        l.flags = g.flags ? g.flags + (size_t)idx * g.spp * g.n_depth * ((g.P + 63) / 64) : nullptr;
+        // planes / flags: [set][lane][sample][bounce]: the lanes of one set are contiguous in lane order = call order within a round of calls
+        for (int k = 0; k < g.n_sets; ++k) {
+            l.plane_sets[k] = g.planes + ((size_t)k * g.n_lanes + idx) * g.spp * g.n_depth * 3 * (size_t)g.P;
+            l.flag_sets[k] = g.flags ? g.flags + ((size_t)k * g.n_lanes + idx) * g.spp * g.n_depth * ((g.P + 63) / 64) : nullptr;
+            if (g.n_sets > 1 && (e = hipEventCreateWithFlags(&l.set_free[k], hipEventDisableTiming)) != hipSuccess) return (int)e;
+        }
+        l.plane = l.plane_sets[0]; l.flags = l.flag_sets[0];
         // under the tile partition every rank used the same (iter, slot, depth) keys; make them rank-unique
         l.ws.slot_bias = g.n_parts > 1 ? g.part * g.P * g.spp : 0;          // fits an int: checked in context_init
     }
@@ -319,13 +329,24 @@ int context_init(Scene* scene) {
         if (g.n_lanes < 2) { g.tiles = false; g.n_lanes = 1; }
     }
     const size_t plane = 3 * (size_t)g.P;
-    // Accumulation (merge_lane): with several planes the default is ORDERED — one plane per sample and, when the context is initialised in MIS mode,
+    // Accumulation (flush_merges): with several planes the default is ORDERED — one plane per sample and, when the context is initialised in MIS mode,
     // per bounce, so that every (pixel, plane) receives one add and the merge can repeat the reference's own sequence of adds
     const size_t n_basic = g.tiles ? 1 : (size_t)g.n_lanes * g.spp;
     g.ordered = n_basic > 1 && g.want_ordered != 0;
     g.n_depth = (g.ordered && current_mode() == PTK_MODE_MIS && g.spp == 1) ? g.traceDepth + 1 : 1;      // (samples per launch: one plane per sample)
     if ((unsigned long long)g.n_depth * plane >= (1ull << 31)) g.n_depth = 1;       // (sample stride must fit 31 bits: then MIS merges the iteration's own sum)
-    const size_t n_planes = n_basic * g.n_depth;
+    // batched merges (PTK_MERGE_BATCH=<n>, n <= lanes): OFF by default — built and measured in round 5 (profiles/r5_ab_batched_merge.txt), bit-identical
+    // (the whole GPU tier ran with it on) and slower: cornell 21.2 -> 20.0, mis_test 1024^2 19.3 -> 16.5, cornell 400^2 12.7 -> 10.8 Grays/s.  The
+    // round-4 upper bound (+2..4 %, two of three merges simply skipped) left out what the real thing costs: the batched merge needs ALL the round's
+    // iterations done, so the stream it runs on stalls until the slowest lane of the round has finished, and that lane's next iteration queues behind it.
+    g.merge_batch = 1; g.n_sets = 1;
+    if (g.ordered && !g.tiles && g.n_lanes > 1) {
+        const char* mb = getenv("PTK_MERGE_BATCH");
+        g.merge_batch = mb ? std::max(1, std::min(atoi(mb), g.n_lanes)) : 1;
+        if (g.merge_batch > 1) g.n_sets = 2;
+    }
+    g.pend_n = 0;
+    const size_t n_planes = n_basic * g.n_depth * g.n_sets;
     if ((rc = dalloc(&g.planes, plane * n_planes))) return rc;
     if ((e = hipMemset(g.planes, 0, sizeof(float) * plane * n_planes)) != hipSuccess) return (int)e;
     if (n_basic > 1) {
@@ -511,16 +532,17 @@ int build_graph(Lane& L, int iter, int mode) {
     hipError_t e;
     // a recapture happens a handful of times per render (mode switch, full_bounces hint): let the lane's queued replays of the
     // old exec finish before it is destroyed (whether the runtime defers the destroy itself is not documented)
-    if (L.graph_exec && hipStreamSynchronize(L.stream) != hipSuccess) return -1000;
-    if (L.graph_exec) { (void)hipGraphExecDestroy(L.graph_exec); L.graph_exec = nullptr; }
-    if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; }
+    Lane::GraphSlot& Q = L.gs[L.cur_set];
+    if (Q.exec && hipStreamSynchronize(L.stream) != hipSuccess) return -1000;
+    if (Q.exec) { (void)hipGraphExecDestroy(Q.exec); Q.exec = nullptr; }
+    if (Q.graph) { (void)hipGraphDestroy(Q.graph); Q.graph = nullptr; }
     if ((e = hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return -1000;
     const int rc = enqueue_iteration(L, iter, mode, true);
-    e = hipStreamEndCapture(L.stream, &L.graph);
-    if (rc) { if (L.graph) { (void)hipGraphDestroy(L.graph); L.graph = nullptr; } return rc; }
-    if (e != hipSuccess || !L.graph) { L.graph = nullptr; return -1000; }
-    if ((e = hipGraphInstantiate(&L.graph_exec, L.graph, nullptr, nullptr, 0)) != hipSuccess) {
-        (void)hipGraphDestroy(L.graph); L.graph = nullptr; L.graph_exec = nullptr;
+    e = hipStreamEndCapture(L.stream, &Q.graph);
+    if (rc) { if (Q.graph) { (void)hipGraphDestroy(Q.graph); Q.graph = nullptr; } return rc; }
+    if (e != hipSuccess || !Q.graph) { Q.graph = nullptr; return -1000; }
+    if ((e = hipGraphInstantiate(&Q.exec, Q.graph, nullptr, nullptr, 0)) != hipSuccess) {
+        (void)hipGraphDestroy(Q.graph); Q.graph = nullptr; Q.exec = nullptr;
         return -1000;
     }
     return 0;
@@ -528,7 +550,8 @@ int build_graph(Lane& L, int iter, int mode) {
 
 int replay_iteration(Lane& L, int iter, int mode) {
     hipError_t e;
-    if (!L.graph_exec || L.graph_mode != mode || L.graph_full != L.full_bounces || L.graph_late != L.gen_late) {
+    Lane::GraphSlot& Q = L.gs[L.cur_set];
+    if (!Q.exec || Q.mode != mode || Q.full != L.full_bounces || Q.late != L.gen_late) {
         const int rc = build_graph(L, iter, mode);
         if (rc == -1000) {
             // capture / instantiate refused by the runtime: same kernels, launched one by one (identical results)
@@ -539,14 +562,14 @@ int replay_iteration(Lane& L, int iter, int mode) {
             return enqueue_iteration(L, iter, mode, false);
         }
         if (rc) return rc;
-        L.graph_mode = mode; L.graph_full = L.full_bounces; L.graph_late = L.gen_late;
+        Q.mode = mode; Q.full = L.full_bounces; Q.late = L.gen_late;
         L.expected_iter = -1;
     }
     if (L.expected_iter != iter) {           // first replay, or the caller jumped in the iteration sequence
         if ((e = hipMemcpyAsync(L.iter_dev, &iter, sizeof(int), hipMemcpyHostToDevice, L.stream)) != hipSuccess) return (int)e;
         if ((e = hipStreamSynchronize(L.stream)) != hipSuccess) return (int)e;     // &iter is a stack address
     }
-    if ((e = hipGraphLaunch(L.graph_exec, L.stream)) != hipSuccess) return (int)e;
+    if ((e = hipGraphLaunch(Q.exec, L.stream)) != hipSuccess) return (int)e;
     L.expected_iter = iter + (g.tiles ? 1 : g.n_lanes) * g.n_shards;
     return 0;
 }
@@ -565,14 +588,44 @@ static void reset_hints() { for (Lane& l : g.lanes) { l.full_bounces = g.traceDe
 // re-initialising.  Measured and dropped: the merges on a stream of their own, so that no lane waits for another — a fourth stream beside three
 // lanes shares a hardware queue with one of them, cornell 21.9 -> 15.2 Grays/s.  Cost against planes that accumulate
 // (ptk_set_ordered_accumulation(0); profiles/r4_ab_ordered_accumulation.txt): cornell BSDF -3 %, MIS -5 %, mis_test 1024^2 MIS -7 %, BSDF -10 %.
-static int merge_lane(Lane& L) {
-    if (!g.ordered) return 0;                            // one plane (the launches add into the image itself), or planes that accumulate (resolve_image)
+// BATCHED (round 5; opt-in, measured slower — see context_init): with merge_batch = L > 1 the merges of a round of L consecutive calls are ONE launch — it reads the L lanes'
+// planes of the round (contiguous: [set][lane][sample][bounce]) in call order and touches the image once per pixel instead of L times; a lane renders
+// alternately into two sets of planes, so its next iteration never waits for the merge of its previous one (only, two calls later, for the merge that
+// zeroed the set it is about to reuse — long done).  The sequence of adds into every pixel is unchanged: bit-identical images.
+static int flush_merges() {
+    if (!g.ordered || g.pend_n == 0) return 0;
     hipError_t e;
-    if (g.last_merged && g.last_merged != L.merged && (e = hipStreamWaitEvent(L.stream, g.last_merged, 0)) != hipSuccess) return (int)e;
-    const int rc = launch_merge_planes(g.image, L.plane, L.flags, g.spp * g.n_depth, g.P, L.stream);
+    Lane& M = g.lanes[g.pend_first + g.pend_n - 1];          // the merge runs behind the last iteration it folds, on that lane's stream
+    for (int k = 0; k < g.pend_n - 1; ++k) {
+        Lane& o = g.lanes[g.pend_first + k];
+        if ((e = hipEventRecord(o.done, o.stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamWaitEvent(M.stream, o.done, 0)) != hipSuccess) return (int)e;
+    }
+    if (g.last_merged && g.last_merged != M.merged && (e = hipStreamWaitEvent(M.stream, g.last_merged, 0)) != hipSuccess) return (int)e;
+    Lane& F = g.lanes[g.pend_first];
+    const int rc = launch_merge_planes(g.image, F.plane_sets[g.pend_set], F.flag_sets[g.pend_set], g.pend_n * g.spp * g.n_depth, g.P, M.stream);
     if (rc) return rc;
-    if ((e = hipEventRecord(L.merged, L.stream)) != hipSuccess) return (int)e;
-    g.last_merged = L.merged;
+    if ((e = hipEventRecord(M.merged, M.stream)) != hipSuccess) return (int)e;
+    g.last_merged = M.merged;
+    if (g.n_sets > 1)
+        for (int k = 0; k < g.pend_n; ++k) {
+            Lane& o = g.lanes[g.pend_first + k];
+            if ((e = hipEventRecord(o.set_free[g.pend_set], M.stream)) != hipSuccess) return (int)e;
+            o.set_busy[g.pend_set] = true;
+        }
+    g.pend_n = 0;
+    return 0;
+}
+// the iteration just enqueued on lane `li` (into its current set) joins the pending batch; the batch is merged when it is full, at the end of a round
+// of lanes, or when the next call would not continue it (callers that jump in the call sequence)
+static int note_unmerged(int li) {
+    if (!g.ordered) return 0;
+    Lane& L = g.lanes[li];
+    if (g.pend_n > 0 && (li != g.pend_first + g.pend_n || L.cur_set != g.pend_set)) { const int rc = flush_merges(); if (rc) return rc; }
+    if (g.pend_n == 0) { g.pend_first = li; g.pend_set = L.cur_set; }
+    ++g.pend_n;
+    if (g.n_sets > 1) L.cur_set ^= 1;
+    if (g.pend_n >= g.merge_batch || li == g.n_lanes - 1) return flush_merges();
     return 0;
 }
 
@@ -583,6 +636,11 @@ static int lane_iteration(Lane& L, int iter, int mode) {
         if (e != hipSuccess) return (int)e;
         L.wait_resolved = false;
     }
+    if (g.n_sets > 1) {
+        // the set this iteration renders into was zeroed by the merge that folded the lane's iteration of two calls ago
+        if (L.set_busy[L.cur_set]) { const hipError_t e = hipStreamWaitEvent(L.stream, L.set_free[L.cur_set], 0); if (e != hipSuccess) return (int)e; L.set_busy[L.cur_set] = false; }
+        L.plane = L.plane_sets[L.cur_set]; L.flags = L.flag_sets[L.cur_set]; L.ws.film_flags = L.flags;
+    }
     L.last_iter = iter;
     g_prof.stream = L.stream;
     note_counts(L);
@@ -590,7 +648,7 @@ static int lane_iteration(Lane& L, int iter, int mode) {
     if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
     else { L.expected_iter = -1; rc = enqueue_iteration(L, iter, mode, false); }
     if (rc || (rc = request_counts(L))) return rc;
-    return merge_lane(L);
+    return g.tiles ? 0 : note_unmerged((int)(&L - &g.lanes[0]));
 }
 
 int render_iteration(unsigned char* pbo, int step) {
@@ -645,7 +703,9 @@ int join_on_lane0() {
 // the image as of the last call, on lane 0's stream after joining the other lanes (event edges, no host wait): the running sum itself (one
 // plane, tiles in flight, ordered accumulation), or ((plane0 + plane1) + plane2) + ... of planes that accumulate
 int resolve_image() {
-    int rc = join_on_lane0();
+    int rc = flush_merges();                 // (batched merges: fold what has been rendered so far)
+    if (rc) return rc;
+    rc = join_on_lane0();
     if (rc) return rc;
     if (g.image != g.planes && !g.ordered) rc = launch_sum_planes(g.planes, g.n_lanes * g.spp, 3 * (size_t)g.P, g.image, g.lanes[0].stream);
     return rc;
@@ -699,7 +759,7 @@ int ptk_set_tiles_in_flight(int tiles) {
     return 0;
 }
 /* Accumulation with several radiance planes (iterations in flight, samples per launch; set before ptk_pathtrace_init): -1 / 1 (default) = ordered —
- * every launch's planes are folded into the image in the reference's order of adds (merge_lane: bit-identical to one iteration at a time);
+ * every launch's planes are folded into the image in the reference's order of adds (flush_merges: bit-identical to one iteration at a time);
  * 0 = the planes accumulate and are summed when the image is read, ((p0 + p1) + p2) + ... (no merge launches: 3-10 % faster, float association
  * differs). */
 int ptk_set_ordered_accumulation(int on) {
@@ -713,7 +773,7 @@ int ptk_set_iterations_in_flight(int lanes) {
     return 0;
 }
 
-static void invalidate_graphs() { for (Lane& l : g.lanes) l.graph_mode = -1; }     // captured launches bake these knobs in: recapture
+static void invalidate_graphs() { for (Lane& l : g.lanes) for (Lane::GraphSlot& q : l.gs) q.mode = -1; }     // captured launches bake these knobs in: recapture
 // The reference's own threaded walk as the work-list walk (pipeline 5) and the traversal counters (whose numbers describe that walk, direction
 // order included) need all six direction copies; a large mesh is uploaded with one (dev_scene.hip).  Re-upload on demand; captured graphs hold
 // the old table's address.
@@ -847,8 +907,9 @@ int ptk_debug_slot_shift(int k0, int k1) { g_debug_slot_shift = k0; g_debug_slot
 int ptk_debug_clear_image(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();
-    int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp * g.n_depth)));
-    if (!rc && g.flags) rc = rc_of(hipMemset(g.flags, 0, (size_t)g.n_lanes * g.spp * g.n_depth * (((size_t)g.P + 63) / 64)));
+    (void)flush_merges(); sync_all();
+    int rc = rc_of(hipMemset(g.planes, 0, sizeof(float) * 3 * (size_t)g.P * (g.tiles ? 1 : (size_t)g.n_lanes * g.spp * g.n_depth * g.n_sets)));
+    if (!rc && g.flags) rc = rc_of(hipMemset(g.flags, 0, (size_t)g.n_lanes * g.spp * g.n_depth * g.n_sets * (((size_t)g.P + 63) / 64)));
     if (!rc && g.image != g.planes) rc = rc_of(hipMemset(g.image, 0, sizeof(float) * 3 * (size_t)g.P));
     return rc ? rc : rc_of(hipDeviceSynchronize());      // null-stream clear vs the lanes' non-blocking streams
 }
@@ -942,7 +1003,7 @@ void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
 // Schedule of the C++ API, chosen at pathtraceInit (the four reference signatures have no room for knobs).  DEFAULT: three iterations in flight +
 // hipGraph replay with ordered accumulation — scene->state.image is bit-identical to one iteration at a time, i.e. to the reference's running sum,
-// in every sample mode (merge_lane; MIS gets one plane per bounce, which is decided by the mode at pathtraceInit: the viewer re-initialises on a
+// in every sample mode (flush_merges; MIS gets one plane per bounce, which is decided by the mode at pathtraceInit: the viewer re-initialises on a
 // sample-mode change, main.cpp:173-201, preview.cpp:247).  Overrides: PTK_IN_FLIGHT=<L> (1 = the reference's own schedule), PTK_TILES=<K>,
 // PTK_GRAPH=0|1, PTK_ORDERED=-1|0|1 (as the ptk_set_* calls, which a host may also make itself before pathtraceInit), PTK_EAGER_IMAGE=1 = refresh
 // scene->state.image after EVERY call like pathtrace.cu:809-810 (a 7.7 MB D2H and a host wait per 0.3 ms iteration at 800 x 800).

@@ -209,6 +209,30 @@ def test_alternative_pipelines(ptk, orc, torch_cuda, pipeline):
         assert np.array_equal(img, ref), name
 
 
+@pytest.mark.parametrize("name,res,depth,mode", [("cornell.txt", (200, 168), 8, "MIS"), ("cornell.txt", (131, 77), 6, "BSDF"), ("mis_test.txt", (256, 256), 16, "MIS"),
+                                                 ("bunny_cornell.txt", (96, 96), 5, "MIS")])
+def test_batched_ordered_merge(ptk, orc, torch_cuda, monkeypatch, name, res, depth, mode):
+    """VERDICT r4 #7, built in round 5 (opt-in, PTK_MERGE_BATCH=<n>; measured slower than one merge per call, profiles/r5_ab_batched_merge.txt): ONE
+    k_merge_planes launch folds the planes of a round of n consecutive calls in call order, lanes alternate between two sets of planes.  The image
+    stays the reference's running sum, bit for bit — also when it is read in the middle of a round and when the caller jumps in the call sequence."""
+    m = MODES[mode]
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    ref = np.zeros((o.P, 3), np.float32); mid = None
+    seq = [1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14]           # (a jump after call 5: the round is cut short)
+    for k, it in enumerate(seq):
+        o.pathtrace(m, it, ref)
+        if k == 4: mid = ref.copy()
+    for batch in ("3", "2"):
+        monkeypatch.setenv("PTK_MERGE_BATCH", batch)
+        s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+        r = ptk.Renderer(s, m, in_flight=3, graph=True)
+        for k, it in enumerate(seq):
+            r.iterate(it)
+            if k == 4: assert np.array_equal(r.image(), mid), batch       # read in the middle of a round (calls 4, 5 of the second one)
+        img = r.image(); r.close(); s.close()
+        assert np.array_equal(img, ref), (batch, int((img != ref).any(axis=1).sum()))
+
+
 TS_CASES = [("cornell.txt", (200, 168), 8, "BSDF"), ("cornell.txt", (200, 168), 8, "MIS"), ("cornell.txt", (131, 77), 5, "DIRECT"),
             ("mis_test.txt", (256, 256), 16, "MIS"), ("mis_test.txt", (256, 256), 16, "BSDF"), ("mis_test2.txt", (216, 216), 8, "DIRECT"),
             ("metallic_analytic.txt", (160, 160), 8, "MIS"), ("metallic_analytic.txt", (160, 160), 8, "BSDF"), ("cornell.txt", (24, 24), 8, "BSDF")]
