@@ -113,3 +113,25 @@ base = wave_cost(v, 32)
 for chunk, thr in ((256, 0.25), (512, 0.25), (512, 0.5), (1024, 0.25), (1024, 0.125), (2048, 0.25)):
     c = pool_cost(v, 32, chunk, 4, thr)
     print(f"pooled walk, 32 slots per wave, 4 waves, chunk {chunk}, refill at {thr:.3f} idle: {c:.0f} wave-iterations = {c / base:.3f} x today's, {c * 32 / v.sum():.2f} x the lane work")
+
+# ---- how wide should a node be?  The same dynamic programme for widths 4 / 8 / 16 over the reference's binary tree (direction-0 copy): expected node
+# visits of a random ray ~ sum over wide nodes of area(node root) / area(tree root); child tests per ray ~ visits x width.
+B = S.bvh_size
+t = bv[:B]
+leaf = (t["end"] - t["start"]) <= 1
+ext = t["pMax"].astype(np.float64) - t["pMin"].astype(np.float64)
+area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
+nleaves = (t["end"] - t["start"]).astype(np.int64)
+for Wd in (4, 8, 16):
+    openc = np.zeros((B, Wd + 1)); node = np.zeros(B)
+    for i in range(B - 1, -1, -1):
+        if leaf[i]: continue
+        L, R = i + 1, i + 2 * int(nleaves[i + 1])
+        def slots(j, k):
+            if leaf[j]: return 0.0
+            return node[j] if k == 1 else min(node[j], openc[j, k])
+        for k in range(2, Wd + 1):
+            best = min(slots(L, j) + slots(R, k - j) for j in range(1, k))
+            openc[i, k] = best if k == 2 else min(best, openc[i, k - 1])
+        node[i] = area[i] + openc[i, Wd]
+    print(f"width {Wd:2d}: expected node visits per ray that enters the root box (SAH measure) {node[0] / area[0]:.2f}; x width = {Wd * node[0] / area[0]:.1f} child tests")
