@@ -291,7 +291,16 @@ def roofline_fused(scene, prof, rays_p, steps, scene_file=None):
     # the contract figure is the rocprofv3 one (the committed summary of the same single-stream command); the live HIP-event figure —
     # which brackets every launch with two event records, ~3 us of dispatch / event latency per launch — stays beside it as frac_hip_events
     frac_rp = alg_per_launch / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS if rp else None
-    bound, bound_note = bound_from_counters(pm.get("counters") or {}, pm.get("traffic_bytes_per_launch"), rp or avg_us)
+    ctr = dict(pm.get("counters") or {})
+    try:          # round 5: where the wait goes (tools/pmc_wait.sh)
+        wj = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_wait.json" % ROUND)))["scenes"][scene_file]
+        k, gk = wj["k_shade_trace"], wj.get("k_shade_trace_gen", {})
+        ctr["wait_split"] = {"source": "profiles/%s_pmc_wait.json" % ROUND, "data_or_barrier": k["waiting_on_data_or_barrier_share_of_wave_cycles"], "to_issue": k["waiting_to_issue_share_of_wave_cycles"],
+                             "to_issue_lds": k.get("waiting_to_issue_lds_share_of_wave_cycles", 0), "gen_data_or_barrier": gk.get("waiting_on_data_or_barrier_share_of_wave_cycles", 0),
+                             "l2_latency": k.get("mean_l1_to_l2_read_latency_cycles", 0), "l2_hit": k.get("l2_hit_rate", 0)}
+    except Exception:
+        pass
+    bound, bound_note = bound_from_counters(ctr, pm.get("traffic_bytes_per_launch"), rp or avg_us)
     return {"bound": bound, "bound_note": bound_note,
             "kernel": "k_shade_trace (pipeline 0: shade + trace per launch)", "achieved": round((frac_rp * HBM_PEAK_GBS) if frac_rp else achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(frac_rp if frac_rp else achieved / HBM_PEAK_GBS, 5),
@@ -328,7 +337,11 @@ def bound_from_counters(c, traffic, launch_us):
     if valu is not None: parts.append("vector ALUs busy %.2f of the launch at 2.4 GHz" % valu)
     if split: parts.append("a wave's lifetime: issuing %.2f, waiting on data or a barrier %.2f, waiting to issue %.2f" % (split.get("issuing", 0), wait or 0, split.get("waiting_to_issue", 0)))
     ws = c.get("wait_split")
-    if ws: parts.append("of the wait: LDS-instruction-attributed %.2f, vector-memory in flight %.2f, the rest (barriers, scalar loads) %.2f" % (ws.get("lds", 0), ws.get("vmem", 0), ws.get("other", 0)))
+    if ws:
+        parts.append("round-5 wait attribution (%s): waiting on data or at a barrier %.2f of the wave's cycles, waiting to issue %.2f (LDS part %.3f); the camera launch — the same trace phase and "
+                     "barriers, no dependent loads at its head — waits on data or barriers for %.2f only: the shading launches' wait is their dependent load chain (window tables -> map word -> records; "
+                     "L1 -> L2 read latency %.0f cycles at an L2 hit rate of %.2f) and the barrier skew it causes, not the barriers themselves" % (
+                         ws.get("source"), ws.get("data_or_barrier", 0), ws.get("to_issue", 0), ws.get("to_issue_lds", 0), ws.get("gen_data_or_barrier", 0), ws.get("l2_latency", 0), ws.get("l2_hit", 0)))
     if hbm is not None and hbm >= 0.6: b = "hbm"
     elif valu is not None and valu >= 0.6: b = "valu"
     else: b = "latency"

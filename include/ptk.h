@@ -176,7 +176,11 @@ int ptk_set_tiles_in_flight(int tiles);
  * the context is initialised in MIS mode, so that every (pixel, plane) receives at most one add (pathtrace.cu:398,486,556,572,
  * 303-311) — and the planes are folded into the image when the iteration is done, in call order and bounce by bounce (ordered
  * accumulation): image = ((image + a_1) + a_2) + ..., the reference's own sequence of adds (pathtrace.cu:600).  The image is
- * BIT-IDENTICAL to one iteration at a time in every sample mode.  Not a reference feature. */
+ * BIT-IDENTICAL to one iteration at a time in every sample mode.  Not a reference feature.
+ * Device memory of the planes: L x S x D x 12 B x W x H, D = traceDepth + 1 when the context is initialised in MIS mode with S = 1, else 1
+ * (cornell.txt 800 x 800 depth 8 MIS, L = 3: 208 MB; 2048 x 2048 depth 16 MIS, L = 3: 2.6 GB) + one flag byte per 64 pixels and plane; when a
+ * sample's planes would exceed 2^31 floats the context falls back to D = 1 (MIS then merges the iteration's own sum: a valid image with another
+ * float association).  ptk_pathtrace_init returns the hipMalloc error if the planes do not fit. */
 int ptk_set_iterations_in_flight(int lanes);
 /* Accumulation policy with several radiance planes (L iterations in flight and / or S samples per launch; set before ptk_pathtrace_init).
  * -1 / 1 (default): ordered, as described above (one small merge launch per call; measured -3 % on cornell.txt BSDF, -5 % MIS, -7..-10 % on the
@@ -249,6 +253,12 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *       any-hit phase between shading and tracing.  Scenes with larger meshes continue each launch with the work-list BVH stage
  *       (stable compaction of the rays that enter the root box, BVH walk over the list, finalize).  While the traversal counters
  *       are enabled the staged kernels of 8 run instead (they keep the counters);
+ *   11 = (round 5, opt-in) k_trace_shade: a launch TRACES and SHADES one bounce (the first one generates the camera rays), traceDepth launches per
+ *       iteration; the hit record never leaves the block, the streams are the reference's PathSegment as three 16-byte records (48 B in, 48 B out per
+ *       surviving path-bounce); the compacted slot of a hit path comes from a decoupled look-back over the blocks' hit counts INSIDE the launch
+ *       (one tagged 64-bit word per block).  Triangle-free scenes without textures / ENV map; elsewhere it behaves as 8; not with tiles in flight.
+ *       Bit-identical; slower than 0 today (every block waits for the slowest earlier block of the launch: 16.7 against 21.3 Grays/s on
+ *       cornell.txt; 23.7 if the wait cost nothing — profiles/r5_ab_trace_shade.txt);
  *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the
  *       survivors, and the window prefix in a separate one-block k_segments launch (7) or in the last block of the shading kernel (8);
  *   1 = like 7, the BVH is walked inside the intersect kernel for every ray, one ray per lane (no k_tail);

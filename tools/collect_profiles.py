@@ -1,10 +1,11 @@
 """Copies the summaries of gpurun_out/final_<round> (tools/refresh_profiles.sh) into profiles/ under <round>_ names.   collect_profiles.py [round]"""
 import glob, os, shutil, sys
-RD = sys.argv[1] if len(sys.argv) > 1 else "r4"
+RD = sys.argv[1] if len(sys.argv) > 1 else "r5"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(R, "gpurun_out", "final_" + RD); dst = os.path.join(R, "profiles")
 pairs = [("bench.json", RD + "_bench.json"), ("bench_driver_style.json", RD + "_bench_driver_style.json"), (RD + "_pmc.json", RD + "_pmc.json"), ("issue_cost.txt", RD + "_issue_cost.txt"),
-         ("other_configs.txt", RD + "_other_configs.txt"), (os.path.join("..", "pmc_timed_" + RD, RD + "_pmc_timed.json"), RD + "_pmc_timed.json")]
+         ("other_configs.txt", RD + "_other_configs.txt"), (RD + "_pmc_wait.json", RD + "_pmc_wait.json"),
+         (RD + "_timeline_cornell.txt", RD + "_timeline_cornell.txt"), (RD + "_timeline_bunny_cornell.txt", RD + "_timeline_bunny_cornell.txt"), (os.path.join("..", "pmc_timed_" + RD, RD + "_pmc_timed.json"), RD + "_pmc_timed.json")]
 for tag in ("cornell", "bunny_cornell"):
     pairs += [(f"bench_under_rocprof_{tag}.json", f"{RD}_{tag}_bench_under_rocprof.json")]
     stats = [(f"stats_{tag}", f"{RD}_{tag}_kernel_stats.csv")]

@@ -8,7 +8,7 @@
 #                  one SQ pass of the contracted flavour (libptk_fma.so)
 #   bench        : the plain default `python3 bench.py` line, and the driver-style `--steps 20 --warmup 5`
 set -o pipefail
-RD=${1:-r4}
+RD=${1:-r5}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/final_$RD
 PART=${2:-all}          # 1: kernel stats + PMC passes; 2: PMC of the timed configuration, bench lines, other configs; all: both (needs ~20 minutes)
@@ -41,6 +41,14 @@ cp $out/${RD}_pmc.json profiles/${RD}_pmc.json          # bench.py reads the com
 python3 tools/collect_profiles.py $RD > /dev/null
 fi
 if [ "$PART" = 1 ]; then find $out -name "*.csv" -size +2M -delete; find $out -name "*.db" -delete; exit 0; fi
+bash tools/pmc_wait.sh $RD > $out/pmc_wait.log 2>&1 || { tail -5 $out/pmc_wait.log; exit 1; }      # where the wait goes (round 5) -> profiles/<round>_pmc_wait.json
+# timelines of the steady state, three iterations in flight (tools/timeline.py): how many kernels run at once, per-queue gaps
+for c in "cornell.txt 0 3 600" "bunny_cornell.txt 0 3 400"; do set -- $c; tag=${1%%.txt}
+  rocprofv3 --kernel-trace --output-format csv -d $out/tl_$tag -o t -- python3 tools/diag/render_loop.py $c > $out/tl_$tag.txt 2> $out/tl_$tag.err || true
+  f=$(find $out/tl_$tag -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { echo "== $c: $(cat $out/tl_$tag.txt) (under rocprofv3 --kernel-trace)"; python3 tools/timeline.py $f; } > profiles/${RD}_timeline_$tag.txt 2>&1
+  rm -rf $out/tl_$tag; cp profiles/${RD}_timeline_$tag.txt $out/
+done
+cp profiles/${RD}_pmc_wait.json $out/      # (files written outside gpurun_out/ do not come back from the GPU box)
 bash tools/pmc_timed.sh $RD > $out/pmc_timed.log 2>&1 || { tail -5 $out/pmc_timed.log; exit 1; }
 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
 python3 bench.py --steps 20 --warmup 5 > $out/bench_driver_style.json 2> $out/bench_driver_style.err || exit 1
