@@ -168,6 +168,11 @@ static bool trace_pipeline(int pipeline) { return pipeline == 0 || pipeline == 1
 // pipeline 11 (round 5): k_trace_shade — trace AND shade a bounce per launch, the hit record never leaves the block (ptk_kernels.hip).  Triangle-free
 // scenes without textures only; not with tiles in flight (the bands' cumulative hit counts ride on k_shade_trace), the per-kernel profiler's
 // intersect / shade split or the traversal counters.  PTK_TRACE_SHADE=0|1 overrides what pipeline 0 picks (A/B runs).
+// k_shade_trace_w (round 5): the fused compact kernel with one wave and one 64-slot window per unit of work.  PTK_WAVE_WINDOWS=0|1 (A/B runs).
+static bool wave_windows_choice() {
+    if (const char* e = getenv("PTK_WAVE_WINDOWS")) return atoi(e) != 0;
+    return false;
+}
 static bool ts_pipeline_wanted(int pipeline) {
     if (pipeline == 11) return true;
     if (pipeline != 0) return false;
@@ -259,12 +264,13 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.tr_valid, slots))) return rc;
     if ((rc = dalloc(&l.ws.tr_heavy, slots))) return rc;
     const size_t blocks = ((size_t)l.capacity + 255) / 256 + 2;
-    if ((rc = dalloc(&l.ws.agg_h, blocks))) return rc;
-    if ((rc = dalloc(&l.ws.hit_pref, blocks + 16))) return rc;
-    if ((rc = dalloc(&l.ws.seg_first_h, blocks + 16))) return rc;
+    const size_t wins = ((size_t)l.capacity + 63) / 64 + 8;               // window tables are sized for 64-slot windows (k_shade_trace_w); 256-slot windows use a quarter
+    if ((rc = dalloc(&l.ws.agg_h, wins))) return rc;
+    if ((rc = dalloc(&l.ws.hit_pref, wins + 16))) return rc;
+    if ((rc = dalloc(&l.ws.seg_first_h, wins + 16))) return rc;
     if ((rc = dalloc(&l.ws.hcounts, (size_t)g.traceDepth + 2))) return rc;
     if ((rc = dalloc(&l.ws.agg_a, blocks))) return rc;
-    if ((rc = dalloc(&l.ws.agg_b, blocks))) return rc;
+    if ((rc = dalloc(&l.ws.agg_b, wins))) return rc;
     if ((rc = dalloc(&l.ws.valid_a, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.ws.valid_b, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.ws.counts, (size_t)g.traceDepth + 2))) return rc;
@@ -272,8 +278,8 @@ int lane_init(Lane& l, int idx) {
     if ((rc = dalloc(&l.ws.list, (size_t)l.capacity))) return rc;
     if ((rc = dalloc(&l.iter_dev, 1))) return rc;
     if ((rc = dalloc(&l.ws.srcidx, (size_t)l.capacity))) return rc;
-    if ((rc = dalloc(&l.ws.seg_pref, blocks + 16))) return rc;
-    if ((rc = dalloc(&l.ws.seg_first, blocks + 16))) return rc;
+    if ((rc = dalloc(&l.ws.seg_pref, wins + 16))) return rc;
+    if ((rc = dalloc(&l.ws.seg_first, wins + 16))) return rc;
     // pipeline 11's look-back tables: one tagged word per block (never cleared) + one accumulating word per group of 32 blocks behind them (zero here,
     // cleared again by every launch's last block)
     if ((rc = dalloc(&l.ws.look, 2 * blocks + 64))) return rc;
@@ -290,6 +296,7 @@ int lane_init(Lane& l, int idx) {
     l.ws.walk = pick_walk(g.pipeline, g.n_lanes);
     l.ws.wide_lpr = pick_lpr(g.n_lanes);            // see k_traverse_wide: pairs when the machine is full, quads for the shortest chain
     l.ws.wide_pool = pick_wide_pool(l.capacity, g.tiles ? 1 : g.n_lanes);
+    l.ws.wave_windows = wave_windows_choice();
     l.ws.capacity = l.capacity;
     l.last_iter = 0;
     return 0;

@@ -185,6 +185,12 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
 // reference's "first in index order among equal distances" (strict t_min > t, pathtrace.cu:228), for any pair order;
 // t > 0 floats order like their bit patterns.  After a barrier the thread whose key is the ray's minimum stores the hit
 // point and the deferred normal for it (a later round can only lower the key, and then overwrites).
+// WAVE = true (round 5, k_shade_trace_w): the "block" is ONE wave — NT = 64 rays, the lane is the thread index, every array belongs to the wave alone —
+// and a barrier is a compiler fence: a wave's LDS instructions execute in issue order, so a later read of any lane sees the earlier writes of all lanes.
+// (No fence instruction: a fence — even at wavefront scope — makes the compiler drain the vector-memory counter, i.e. wait for the path stores that are
+// meant to overlap the tracing: measured +14 us on the camera launch.  The compiler barrier keeps the program order of the LDS accesses.)
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+template <bool WAVE> __device__ __forceinline__ void group_sync() { if (WAVE) wave_sync(); else __syncthreads(); }
 // LDS the block-cooperative closest-hit search works in (24.1 KB for 256 threads)
 struct TraceLds {
     float4* ray;                 // [2 * NT]  origins [0, NT), directions [NT, 2 NT) of the block's rays: two planes, so that the 16-byte reads of the pair
@@ -197,12 +203,13 @@ struct TraceLds {
     int* cnt;                    // [NT / 64]
 };
 // RAYS_IN_LDS: L.ray already holds the rays (written by other threads of the block, a barrier since); else every thread stores its own
-template <int NT, bool RAYS_IN_LDS, int LP = 16>       // LP: primitives per pass of the pair list (list = NT * LP entries)
+template <int NT, bool RAYS_IN_LDS, int LP = 16, bool WAVE = false>       // LP: primitives per pass of the pair list (list = NT * LP entries)
 __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, bool active, f3 ro, f3 rd, Analytic& a) {
+    static_assert(!WAVE || NT == 64, "a wave-level group is one wave");
     constexpr int NW = NT / 64;
     constexpr int RB = NT == 512 ? 9 : 8;                 // bits of the ray index inside a list entry
     float4* s_ray = L.ray; float2* s_res = L.res; unsigned long long* s_best = L.best; unsigned short* s_list = L.list; int* s_cnt = L.cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (!RAYS_IN_LDS) {
         s_ray[tid] = make_float4(ro.x, ro.y, ro.z, 0.f);
         s_ray[NT + tid] = make_float4(rd.x, rd.y, rd.z, 0.f);
@@ -229,7 +236,7 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
             if (lane == 63) s_cnt[wid] = incl;
-            __syncthreads();                              // also publishes s_ray / s_best (first pass) and ends the previous pass's reads
+            group_sync<WAVE>();                              // also publishes s_ray / s_best (first pass) and ends the previous pass's reads
             int woff_c = 0, woff_s = 0, Tc = 0, Ts = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -240,10 +247,15 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
             int oc = woff_c + ((incl - v) & 0xffff), os = Tc + woff_s + ((incl - v) >> 16);
             for (unsigned m = c.cube; m; m &= m - 1u) s_list[oc++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
             for (unsigned m = c.sphere; m; m &= m - 1u) s_list[os++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
-            __syncthreads();
+            group_sync<WAVE>();
             const int T = Tc + Ts;
-            for (int r0 = 0; r0 < T; r0 += NT) {
-                const int pi = r0 + tid;
+            // WAVE: a round of 64 lanes would usually MIX cube and sphere pairs and then run both tests (the 256-lane list mixes them in one wave of
+            // four at most): cube rounds first, sphere rounds behind them — the sphere part of the list starts at a multiple of 64 (measured: the
+            // mixed rounds cost k_shade_trace_w 27 % more vector instructions than k_shade_trace)
+            const int Tc_pad = WAVE ? (Tc + NT - 1) / NT * NT : Tc;
+            for (int r0 = 0; r0 < Tc_pad + Ts; r0 += NT) {
+                int pi = r0 + tid;
+                if (WAVE) pi = pi < Tc_pad ? (pi < Tc ? pi : T) : Tc + (pi - Tc_pad);      // (padding lanes: no pair)
                 unsigned long long key = ~0ull;
                 int r = 0;
                 f3 P = mk3(0, 0, 0), NSv = mk3(0, 0, 0);
@@ -265,14 +277,14 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
                         atomicMin(&s_best[r], key);
                     }
                 }
-                __syncthreads();
+                group_sync<WAVE>();
                 if (key != ~0ull && s_best[r] == key) {
                     s_res[3 * r] = make_float2(P.x, P.y);
                     s_res[3 * r + 1] = make_float2(P.z, NSv.x);
                     s_res[3 * r + 2] = make_float2(NSv.y, NSv.z);
                 }
             }
-            __syncthreads();
+            group_sync<WAVE>();
         }
     }
     a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0);
@@ -289,12 +301,13 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
 // result is a boolean OR over the primitives — order-independent, and the primitives the candidate test culls provably miss (returns 0,
 // tests/test_candidate_margin.py) — so it equals the per-lane loop of occluded_analytic.  All NT threads must call it; ends with a barrier.
 //   L.ray[r] = (origin, minT), L.ray[NT + r] = (direction, -) of shadow ray r, written by thread r before the caller's last barrier.
-template <int NT, int LP>
+template <int NT, int LP, bool WAVE = false>
 __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, unsigned long long* s_occ, bool active, f3 ro, f3 rd) {
+    static_assert(!WAVE || NT == 64, "a wave-level group is one wave");
     constexpr int NW = NT / 64;
     constexpr int RB = NT == 512 ? 9 : 8;
     const float4* s_ray = L.ray; unsigned short* s_list = L.list; int* s_cnt = L.cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int base = 0; base < S.n_geoms; base += 32) {
         const int n = (S.n_geoms - base) < 32 ? (S.n_geoms - base) : 32;
         const Cand call = analytic_candidates(S, base, n, ro, rd);
@@ -308,7 +321,7 @@ __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const Ge
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
             if (lane == 63) s_cnt[wid] = incl;
-            __syncthreads();
+            group_sync<WAVE>();
             int woff_c = 0, woff_s = 0, Tc = 0, Ts = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -319,10 +332,12 @@ __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const Ge
             int oc = woff_c + ((incl - v) & 0xffff), os = Tc + woff_s + ((incl - v) >> 16);
             for (unsigned m = c.cube; m; m &= m - 1u) s_list[oc++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
             for (unsigned m = c.sphere; m; m &= m - 1u) s_list[os++] = (unsigned short)(tid | (__builtin_ctz(m) << RB));
-            __syncthreads();
+            group_sync<WAVE>();
             const int T = Tc + Ts;
-            for (int r0 = 0; r0 < T; r0 += NT) {
-                const int pi = r0 + tid;
+            const int Tc_pad = WAVE ? (Tc + NT - 1) / NT * NT : Tc;      // (cube rounds, then sphere rounds: see analytic_closest_lds)
+            for (int r0 = 0; r0 < Tc_pad + Ts; r0 += NT) {
+                int pi = r0 + tid;
+                if (WAVE) pi = pi < Tc_pad ? (pi < Tc ? pi : T) : Tc + (pi - Tc_pad);
                 if (pi < T) {
                     const unsigned e = s_list[pi];
                     const int r = (int)(e & ((1u << RB) - 1u));
@@ -336,7 +351,7 @@ __device__ __forceinline__ void analytic_anyhit_lds(const SceneView& S, const Ge
                     if (t > 0.0f && minT - 1e-5f > t && (double)fabsf(t - minT) > 1e-2) atomicOr(&s_occ[r >> 6], 1ull << (r & 63));
                 }
             }
-            __syncthreads();                              // the list is rewritten by the next pass; the last one publishes s_occ
+            group_sync<WAVE>();                              // the list is rewritten by the next pass; the last one publishes s_occ
         }
     }
 }
@@ -1452,7 +1467,8 @@ struct GenArgs { DevCamera cam; int trace_depth, n_parts, part, tile_rows, n_pix
 // segments_block for the fused launches: the window prefix of the survivor counts (pref / first / next live count) AND the prefix of the hit
 // counts (hit_pref) in ONE pass — the last block of a launch runs alone, its time is on every lane's critical path (two separate scans took
 // twice the barriers).  Four consecutive windows per thread; agg_h == nullptr: no hit prefix (SPLIT: k_finalize2 builds it).
-template <int NT>
+template <int NT, int WIN = PTK_BLOCK, int WPT = 4>      // WIN: slots per window (64 for k_shade_trace_w's wave windows); WPT: consecutive windows per thread and pass (the
+                                                         // loads of a pass are in flight together: the last block runs alone, each pass is one exposed round trip)
 __device__ __forceinline__ void segments_block2(int n_prev, const int* __restrict__ agg_s, const int* __restrict__ agg_h, int* __restrict__ pref, int* __restrict__ first,
                                                 int* __restrict__ hit_pref, int* __restrict__ count_out, int* iter_advance, int iter_stride,
                                                 int* __restrict__ first_h = nullptr, int* __restrict__ hcount_out = nullptr,
@@ -1461,18 +1477,32 @@ __device__ __forceinline__ void segments_block2(int n_prev, const int* __restric
     __shared__ int s_ws[NW], s_wh[NW];
     __shared__ int s_carry_s, s_carry_h;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nw = n_prev > 0 ? (n_prev + PTK_BLOCK - 1) / PTK_BLOCK : 0;
+    const int nw = n_prev > 0 ? (n_prev + WIN - 1) / WIN : 0;
     if (tid == 0) { s_carry_s = 0; s_carry_h = 0; }
     __syncthreads();
-    for (int base = 0; base < nw; base += 4 * NT) {
-        const int idx = base + 4 * tid;
-        int cs[4] = {0, 0, 0, 0}, ch[4] = {0, 0, 0, 0};
+    // the counts of pass p + 1 are requested before pass p is processed: the passes are serial (carry), their load round trips need not be
+    int ns[WPT], nh[WPT];
+    auto fetch = [&](int base, int* os, int* oh) {
+        const int idx = base + WPT * tid;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (idx + k < nw) {
-            cs[k] = __hip_atomic_load(agg_s + idx + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (agg_h) ch[k] = __hip_atomic_load(agg_h + idx + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < WPT; ++k) {
+            os[k] = 0; oh[k] = 0;
+            if (idx + k < nw) {
+                os[k] = __hip_atomic_load(agg_s + idx + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (agg_h) oh[k] = __hip_atomic_load(agg_h + idx + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        const int vs = (cs[0] + cs[1]) + (cs[2] + cs[3]), vh = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+    };
+    fetch(0, ns, nh);
+    for (int base = 0; base < nw; base += WPT * NT) {
+        const int idx = base + WPT * tid;
+        int cs[WPT], ch[WPT];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) { cs[k] = ns[k]; ch[k] = nh[k]; }
+        if (base + WPT * NT < nw) fetch(base + WPT * NT, ns, nh);
+        int vs = 0, vh = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) { vs += cs[k]; vh += ch[k]; }
         int is = vs, ih = vh;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(is, o, 64), c = __shfl_up(ih, o, 64); if (lane >= o) { is += a; ih += c; } }
@@ -1484,15 +1514,15 @@ __device__ __forceinline__ void segments_block2(int n_prev, const int* __restric
         const int carry_s = s_carry_s, carry_h = s_carry_h;
         int es = carry_s + offs + is - vs, eh = carry_h + offh + ih - vh;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < WPT; ++k) {
             if (idx + k < nw) {
                 pref[idx + k] = es;
                 if (agg_h) hit_pref[idx + k] = eh;
-                const int B = (es + PTK_BLOCK - 1) / PTK_BLOCK;
-                if (cs[k] > 0 && B * PTK_BLOCK < es + cs[k]) first[B] = idx + k;
+                const int B = (es + WIN - 1) / WIN;
+                if (cs[k] > 0 && B * WIN < es + cs[k]) first[B] = idx + k;
                 if (first_h) {                                   // the same table over the HIT order (the order the next launch shades in)
-                    const int Bh = (eh + PTK_BLOCK - 1) / PTK_BLOCK;
-                    if (ch[k] > 0 && Bh * PTK_BLOCK < eh + ch[k]) first_h[Bh] = idx + k;
+                    const int Bh = (eh + WIN - 1) / WIN;
+                    if (ch[k] > 0 && Bh * WIN < eh + ch[k]) first_h[Bh] = idx + k;
                 }
             }
             es += cs[k]; eh += ch[k];
@@ -1934,6 +1964,220 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_shade_trace_w (round 5) — k_shade_trace's compact layout with WAVE WINDOWS: the unit of work is one wave and its own 64-slot window.
+//
+// Why: by the counters (profiles/r5_pmc_wait.json) a wave of k_shade_trace spends 0.58 of its cycles waiting on data or at a barrier — and the
+// camera launch, which has the same trace phase and barriers but no loads at its head and no shading, still 0.42: most of the wait is the block's
+// ~18 barriers, each of which holds four waves (on four SIMDs, each shared with six other waves) for the slowest of them.  Here a block is four
+// INDEPENDENT waves that share only the staged primitives and materials (one barrier at the start, one at the end for the window bookkeeping):
+// wave w of block b shades hits [64 (4 b + w), + 64) of the previous bounce, keeps its survivors in window 4 b + w of the next buffer, and traces
+// them — every former barrier is a compiler fence (a wave's LDS instructions execute in issue order), the counting sort, the survivor ranks and
+// the inverse map are ballots and lane permutes, the pair list of the closest-hit search is balanced over the wave's 64 lanes.  Same streams,
+// same tables (in units of 64 slots), same keys, same order of additions: bit-identical to k_shade_trace.
+// ------------------------------------------------------------------------------------------------------------------
+#define PTK_WW 64
+template <int MODE, bool GEN>
+__global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ? PTK_FUSED_WAVES_GEN : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF))))
+k_shade_trace_w(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n, TraceIO io, FilmArgs film,
+                int spp, int slot_bias, SegTail2 tail) {
+    constexpr int NT = PTK_BLOCK, NW = NT / 64, WW = PTK_WW, NKEY = 6, MATS = 16, LP = 8;
+    __shared__ DevMaterial s_mats[MATS];                            // shared by the block's waves (read-only after the first barrier)
+    __shared__ float4 s_stage_all[NW][4 * WW];                      // per wave: rays (2 KB), winners' hit points + deferred normals (1.5 KB), winner keys (0.5 KB)
+    __shared__ unsigned short s_list_all[NW][WW * LP];              // per wave: the pair list of its closest-hit / any-hit search
+    __shared__ int s_tcnt[NW];
+    __shared__ unsigned long long s_occ_all[NW];
+    __shared__ int s_last;
+    constexpr bool DEFER_NEE = !GEN && MODE != PTK_MODE_BSDF;
+
+    const int step = iter_ptr ? *iter_ptr : iter_arg;
+    const int n = GEN ? gen.n_pix * spp : (d_n ? *d_n : n_arg);      // hits of the bounce being shaded (GEN: rays to generate)
+    const Film img = {film, depth};
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
+    if (b * NT >= n) {
+        if (n <= 0 && b == 0) {
+            if (tail.hit_pref && tid < 8) tail.hit_pref[tid] = 0;
+            if (tail.hcount_out && tid == 0) *tail.hcount_out = 0;
+            if (tail.cum_out && tid == 0) { const int at = cum_row(step, tail.ring_div, tail.cum_stride) + depth + 1; tail.cum_out[at] = cum_read(tail.cum_prev, 0, at); }
+            segments_block<NT, false>(0, io.agg_s, tail.pref, tail.first, tail.count_out, tail.iter_advance, tail.iter_stride);
+        }
+        return;
+    }
+    const GeomStage gs = stage_geoms(S, false);
+    const MatTable mt = stage_materials<NT, MATS>(S, s_mats);       // ends with the block's first barrier: primitives and materials are staged
+    float4* s_ray = s_stage_all[wid];
+    float2* s_res = reinterpret_cast<float2*>(s_ray + 2 * WW);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + 2 * WW + (3 * WW) / 2);
+    // sorted position -> lane (before the shading phase), later hit rank -> lane | type << 8 (after the trace phase): in the wave's pair-list space, which
+    // is only in use between the two (23.0 KB per block with the staged primitives of cornell.txt = seven blocks per CU; with a table of its own: six)
+    int* s_tab = reinterpret_cast<int*>(s_list_all[wid]);
+    const TraceLds L = {s_ray, s_res, s_best, s_list_all[wid], &s_tcnt[wid]};
+    const int Wn = __builtin_amdgcn_readfirstlane(b * NW + wid);    // this wave's window
+    const bool wave_live = Wn * WW < n;                            // (wave-uniform)
+    const int i = Wn * WW + lane;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int total = 0, hits = 0;
+    if (wave_live) {
+        int alive = 0, my_rank = -1;
+        ShadowReq rq; rq.on = false; rq.slot = s_ray + 2 * WW + lane; rq.dstride = WW; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
+        int gen_pixw = 0;
+        const bool gen_late = GEN && gen.late_stores != 0;
+        if (DEFER_NEE && lane == 0) s_occ_all[wid] = 0ull;
+        if (GEN) {
+            total = min(WW, n - Wn * WW);
+            if (i < n) {
+                alive = 1; my_rank = lane;
+                const int n_pix = gen.n_pix;
+                const int sidx = i / n_pix, jp = i - sidx * n_pix;
+                const int iter = (step - 1) * spp + sidx + 1;
+                const int lr = jp / gen.cam.W, x = jp - lr * gen.cam.W;
+                const int y = ((lr / gen.tile_rows) * gen.n_parts + gen.part) * gen.tile_rows + (lr % gen.tile_rows);
+                Rng rng = make_rng(x, y, iter);                       // argument order of pathtrace.cu:148: (iter:=x, index:=y, depth:=iter)
+                const f2 r = sample2D(rng);
+                const float fx = static_cast<float>(static_cast<float>(x) + ((double)r.x - 0.5) - gen.cam.W * 0.5f);
+                const float fy = static_cast<float>(static_cast<float>(y) + ((double)r.y - 0.5) - gen.cam.H * 0.5f);
+                const f3 d = normalize(gen.cam.view - gen.cam.right * gen.cam.plx * fx - gen.cam.up * gen.cam.ply * fy);
+                gen_pixw = (sidx << 24) | (x + y * gen.cam.W);
+                if (!gen_late) {
+                    st4(io.nxt.o_pix, i, make_float4(d.x, d.y, d.z, __int_as_float(gen_pixw)));
+                    st4(io.nxt.d_bnc, i, make_float4(1.f, 1.f, 1.f, __int_as_float(gen.trace_depth)));
+                    if (MODE == PTK_MODE_MIS) st4(io.nxt.col_pdf, i, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, -1.f));
+                }
+                s_ray[lane] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
+                s_ray[WW + lane] = make_float4(d.x, d.y, d.z, 0.f);
+            }
+        } else {
+            // ---- shading phase, hit-dense: lane shades hit i of the previous bounce; its compacted slot — the reference's RNG key — is i itself
+            const int iter = (step - 1) * spp + 1;
+            const int slot_off = slot_bias + cum_read(tail.cum_prev, cum_row(step, tail.ring_div, tail.cum_stride), depth);
+            const int nw_prev = depth > 0 ? (d_n[-1] + WW - 1) / WW : (gen.n_pix * spp + WW - 1) / WW;
+            const int w0 = __builtin_amdgcn_readfirstlane(io.first_h[Wn]);
+            const int h0 = io.hit_pref[w0], h1 = io.hit_pref[w0 + 1], h2 = io.hit_pref[w0 + 2], h3 = io.hit_pref[w0 + 3], h4 = io.hit_pref[w0 + 4];
+            int src_mine = 0, key = NKEY - 1, slot_mine = 0;
+            if (i < n) {
+                int k = (i >= h1) + (i >= h2) + (i >= h3) + (i >= h4);
+                int base = k == 0 ? h0 : (k == 1 ? h1 : (k == 2 ? h2 : (k == 3 ? h3 : h4)));
+                if (k == 4) k = sparse_window(io.hit_pref, w0 + 4, nw_prev, i, base) - w0;
+                const int at = (w0 + k) * WW + (i - base);
+                const int word = __float_as_int(io.hcur.t_n[4 * (size_t)at + 3]) & 0x3fffffff;
+                src_mine = (w0 + k) * WW + (word & 0xff);
+                key = word >> 8; slot_mine = i + slot_off;
+            }
+            // counting sort by material type inside the wave: ballots; sorted position -> lane through the wave's table
+            int rank = 0, n_active = 0;
+#pragma unroll
+            for (int k = 0; k < NKEY; ++k) {
+                const unsigned long long bk = __ballot(key == k);
+                const int tot = __popcll(bk);
+                if (k < NKEY - 1) n_active += tot;
+                if (key == k) rank += __popcll(bk & lt);
+                else if (key > k) rank += tot;
+            }
+            s_tab[rank] = lane;
+            wave_sync();
+            const int pj = s_tab[lane];                              // the lane whose path this thread shades (its position in the original order)
+            const int slot = __shfl(slot_mine, pj, 64), ps = __shfl(src_mine, pj, 64);
+            PathRegs p;
+            p.o = mk3(0, 0, 0); p.d = mk3(0, 0, 0); p.col = mk3(0, 0, 0); p.pix = 0; p.bounces = 0; p.prevPdf = 0.f;
+            if (lane < n_active) {
+                Hit h;
+                const float4 q0 = ld4(io.hcur.t_n, ps), q1 = ld4(io.hcur.p_mat, ps), a4 = ld4(io.cur.o_pix, ps), b4 = ld4(io.cur.d_bnc, ps);
+                h.t = 1.0f; h.n = mk3(q0.x, q0.y, q0.z); h.p = mk3(q1.x, q1.y, q1.z); h.mat = __float_as_int(q1.w);
+                h.uv.x = 0.f; h.uv.y = 0.f; h.geom = -1; h.tri = -1;
+                p.pix = __float_as_int(a4.w);
+                p.d = mk3(a4.x, a4.y, a4.z); p.bounces = __float_as_int(b4.w);
+                p.col = mk3(b4.x, b4.y, b4.z); p.prevPdf = -1.f;
+                if (MODE == PTK_MODE_MIS) {
+                    const float4 c4 = ld4(io.cur.col_pdf, ps);
+                    p.o = mk3(c4.x, c4.y, c4.z); p.prevPdf = c4.w;
+                    h.geom = __float_as_int(q1.w);
+                    h.mat = gs.on ? __float_as_int(gs.xf[(size_t)h.geom * PTK_XF_FLOATS + 34]) : S.geoms[h.geom].materialid;
+                }
+                rq.pix = p.pix;
+                alive = shade_path<MODE>(S, gs, mt, iter, slot, depth, h, p, img, DEFER_NEE ? &rq : nullptr);
+            }
+            // survivor rank in the ORIGINAL (dense) order — the next bounce's compacted order, hence its RNG keys: the path of original position L was
+            // shaded by the thread at sorted position rank(L)
+            const int alive_orig = __shfl(alive, rank, 64);
+            const unsigned long long m = __ballot(alive_orig != 0);
+            total = __popcll(m);
+            if (alive) {
+                my_rank = __popcll(m & ((1ull << pj) - 1ull));
+                const int s2 = Wn * WW + my_rank;
+                st4(io.nxt.o_pix, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.pix)));
+                st4(io.nxt.d_bnc, s2, make_float4(p.col.x, p.col.y, p.col.z, __int_as_float(p.bounces)));
+                if (MODE == PTK_MODE_MIS) st4(io.nxt.col_pdf, s2, make_float4(p.o.x, p.o.y, p.o.z, p.prevPdf));
+                s_ray[my_rank] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix));          // hand the new ray to the lane that traces it
+                s_ray[WW + my_rank] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces));
+            }
+        }
+        wave_sync();
+        if (DEFER_NEE && __ballot(rq.on) != 0ull) {                  // (wave-uniform) shadow phase of the wave's next-event samples (lightSample.h:59-139)
+            const TraceLds Lsh = {s_ray + 2 * WW, nullptr, nullptr, s_list_all[wid], &s_tcnt[wid]};
+            f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0); int s_pix = 0;
+            if (rq.on) { const float4 o4 = rq.slot[0], d4 = rq.slot[WW]; so = mk3(o4.x, o4.y, o4.z); sd = mk3(d4.x, d4.y, d4.z); s_pix = __float_as_int(d4.w); }
+            analytic_anyhit_lds<WW, LP, true>(S, gs, Lsh, &s_occ_all[wid], rq.on, so, sd);
+            const bool occ = (s_occ_all[wid] >> lane) & 1ull;
+            if (rq.on && !occ) add_radiance(img, s_pix, rq.contrib);
+            wave_sync();
+        }
+        // ---- trace phase: lane t < total traces survivor t of the window
+        if (total > 0) {                                             // (wave-uniform)
+            const bool active = lane < total;
+            f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+            if (active) { const float4 o4 = s_ray[lane], d4 = s_ray[WW + lane]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z); }
+            Analytic a;
+            analytic_closest_lds<WW, true, LP, true>(S, gs, L, active, ro, rd, a);
+            const int flag = active && a.geom >= 0;
+            const int slot = Wn * WW + lane;
+            Hit h;
+            h.t = -1.f; h.n = mk3(0, 0, 0); h.p = mk3(0, 0, 0); h.uv.x = h.uv.y = 0.f; h.mat = 0; h.geom = -1; h.tri = -1;
+            if (flag) analytic_record_staged(gs.xf, a, h);
+            const unsigned long long hb = __ballot(flag != 0);
+            hits = __popcll(hb);
+            // the normal's spare word of slot p: sign = slot p itself missed; low bits = the window's inverse map for hit-dense shading (hit number p of
+            // this window sits at slot (word & 0xff), material type (word >> 8) & 0x7f)
+            const int rank_h = __popcll(hb & lt), type = flag ? S.mats[h.mat].type : 0;
+            if (flag) s_tab[rank_h] = lane | (type << 8);
+            wave_sync();
+            if (active) {
+                const int word = (lane < hits ? s_tab[lane] : 0) | (flag ? 0 : (int)0x80000000u);
+                st4(io.hnxt.t_n, slot, make_float4(h.n.x, h.n.y, h.n.z, __int_as_float(word)));
+                if (flag) {
+                    st4(io.hnxt.p_mat, slot, make_float4(h.p.x, h.p.y, h.p.z, __int_as_float(MODE == PTK_MODE_MIS ? h.geom : h.mat)));
+                    if (GEN && gen_late) {
+                        st4(io.nxt.o_pix, slot, make_float4(rd.x, rd.y, rd.z, __int_as_float(gen_pixw)));
+                        st4(io.nxt.d_bnc, slot, make_float4(1.f, 1.f, 1.f, __int_as_float(gen.trace_depth)));
+                        if (MODE == PTK_MODE_MIS) st4(io.nxt.col_pdf, slot, make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, -1.f));
+                    }
+                }
+            }
+        }
+        if (lane == 0) {                                             // this window's survivor and hit counts
+            __hip_atomic_store(io.agg_s + Wn, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(io.agg_h + Wn, hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();                                                 // the block's windows are published: the only other barrier of the block
+    // the last block of the launch builds the window tables (as segments_tail2, in units of 64-slot windows)
+    const int nb = (n + NT - 1) / NT, ng = (nb + PTK_SEG_GROUP - 1) / PTK_SEG_GROUP;
+    if (tid == 0) {
+        const int grp = b / PTK_SEG_GROUP;
+        const int gsize = min(PTK_SEG_GROUP, nb - grp * PTK_SEG_GROUP);
+        int last = 0;
+        if (__hip_atomic_fetch_add(tail.done + 32 * (grp + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1)
+            last = __hip_atomic_fetch_add(tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int k = tid; k <= ng; k += NT) __hip_atomic_store(tail.done + 32 * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    segments_block2<NT, WW, 4>(n, io.agg_s, io.agg_h, tail.pref, tail.first, tail.hit_pref, tail.count_out, tail.iter_advance, tail.iter_stride,
+                            tail.first_h, tail.hcount_out, tail.cum_prev, tail.cum_out, cum_row(step, tail.ring_div, tail.cum_stride) + depth + 1);
+    if (tid == 0 && tail.ray_total) atomicAdd(tail.ray_total, (unsigned long long)*tail.count_out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // k_trace_shade (round 5, pipeline 11) — TRACE bounce d and SHADE bounce d in one launch, for triangle-free scenes.
 //
 // k_shade_trace fuses the other way round (shade d-1, trace d) because the reference keys the shading RNG by the COMPACTED slot of a hit path
@@ -2272,6 +2516,7 @@ struct TailArgs {
     // ... by a HIT-DENSE launch (every fused layout but SPLIT): the tail enumerates the hits of bounce depth0 like that launch's successor would
     // (hit prefix + first_h + the inverse-map words), never its misses — and takes over as soon as a bounce has few HITS, however many rays
     int hit_dense; const int* hit_pref; const int* first_h; const int* nhits;
+    int win;                                 // slots per window of the traced stream: 256, or 64 after k_shade_trace_w
     int* hcounts;                            // (may be null) hcounts[d] = hits of bounce d, kept up to date for the host's hand-over hint
     const int* cum_prev; int* cum_out; int cum_stride, ring_div;      // tiles in flight (Workspace::cum_*), null = off
 };
@@ -2310,14 +2555,14 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
                 int src;
                 if (traced && A.hit_dense) {
                     // hit i of the traced bounce -> window (hit prefix) -> slot (inverse-map word of the window's (i - base)-th slot)
-                    const int nw = (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK;
-                    const int w0 = A.first_h[i / PTK_BLOCK];
+                    const int nw = (*A.nshaded + A.win - 1) / A.win;
+                    const int w0 = A.first_h[i / A.win];
                     int k = 0, base = A.hit_pref[w0];
                     while (k < 4 && i >= A.hit_pref[w0 + k + 1]) { ++k; base = A.hit_pref[w0 + k]; }
                     if (k == 4) k = sparse_window(A.hit_pref, w0 + 4, nw, i, base) - w0;
-                    const int at = (w0 + k) * PTK_BLOCK + (i - base);
+                    const int at = (w0 + k) * A.win + (i - base);
                     const int word = (A.compact ? __float_as_int(A.hits0.t_n[4 * (size_t)at + 3]) : A.hr0[at]) & 0x3fffffff;
-                    src = (w0 + k) * PTK_BLOCK + (word & 0xff);
+                    src = (w0 + k) * A.win + (word & 0xff);
                 } else src = gather_source(G, i / PTK_BLOCK, i, n, G.pref ? (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK : 0);
                 if (traced && A.compact) {                                  // k_shade_trace's compact streams: (d, pix) (col, bounces) (n, rank) (p, mat)
                     const float4 a4 = ld4(cur.o_pix, src), b4 = ld4(cur.d_bnc, src), h0 = ld4(A.hits0.t_n, src);
@@ -2706,10 +2951,11 @@ int launch_bounce_staged(const SceneView& S, int mode, int iter, int depth, int 
 // fused pipeline: one launch shades bounce dt - 1 (paths / hits / ranks of `cur`) — or, gen, generates the camera rays — and traces
 // bounce dt into `nxt`.  Scenes with triangles continue with the work-list BVH stage on the survivors' physical slots.
 template <int MODE, bool GEN>
-static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
+static int launch_shade_trace_t(const SceneView& S, bool split, bool compact, bool wave_windows, const GenArgs& G, int iter, const int* iter_ptr, int depth, int capacity, const int* d_n,
                                 const TraceIO& io, const FilmArgs& film, int spp, int slot_bias, const SegTail2& tail, hipStream_t st) {
     const int g = grid_for(capacity);
     if (split) k_shade_trace<MODE, GEN, true, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
+    else if (compact && wave_windows) k_shade_trace_w<MODE, GEN><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
     else if (compact) k_shade_trace<MODE, GEN, false, true><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
     else k_shade_trace<MODE, GEN, false, false><<<g, PTK_BLOCK, stage_bytes(S), st>>>(S, G, iter, iter_ptr, depth, capacity, d_n, io, film, spp, slot_bias, tail);
     return launch_rc();
@@ -2726,6 +2972,7 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     S.slim_hits = (S.n_tex == 0 && mode != PTK_MODE_MIS) ? 1 : 0;
     const bool split = S.n_tris > 0 && !ws.inline_bvh && ws.queue && ws.list;       // inline_bvh (tiny mesh): the walk runs inside k_shade_trace's trace phase
     const bool compact = !split && trace_compact(S, mode);
+    const bool ww = compact && ws.wave_windows && S.lds_geoms > 0;          // k_shade_trace_w: 64-slot windows, one per wave
     GenArgs G;
     G.cam.W = cam.resolution.x; G.cam.H = cam.resolution.y;
     G.cam.pos = mk3(cam.position.x, cam.position.y, cam.position.z);
@@ -2751,14 +2998,14 @@ int launch_shade_trace(const SceneView& S_in, int mode, bool gen, const ::Camera
     int rc;
     if (gen) {
         switch (mode) {                 // (the mode only matters for the hit-record layout the next launch expects: same kernel body)
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;   // (the MIS layouts carry the origin)
-        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, true>(S, split, compact, ww, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;   // (the MIS layouts carry the origin)
+        default: rc = launch_shade_trace_t<PTK_MODE_BSDF, true>(S, split, compact, ww, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
         }
     } else {
         switch (mode) {
-        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
-        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
-        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
+        case PTK_MODE_BSDF: rc = launch_shade_trace_t<PTK_MODE_BSDF, false>(S, split, compact, ww, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
+        case PTK_MODE_DIRECTLI: rc = launch_shade_trace_t<PTK_MODE_DIRECTLI, false>(S, split, compact, ww, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
+        case PTK_MODE_MIS: rc = launch_shade_trace_t<PTK_MODE_MIS, false>(S, split, compact, ww, G, iter, ws.iter_dev, depth, capacity, d_n, io, film_of(img, ws), ws.spp, sbias, tail, st); break;
         default: rc = PTK_E_BADARG;
         }
     }
@@ -2845,6 +3092,7 @@ int launch_tail(const SceneView& S_in, int mode, int iter, int depth0, int trace
     A.nshaded = (depth0 > 0 ? (hit_dense ? ws.hcounts : ws.counts) + (depth0 - 1) : ws.counts);
     A.hit_dense = (hit_dense && depth0 > 0) ? 1 : 0; A.hit_pref = ws.hit_pref; A.first_h = ws.seg_first_h; A.nhits = ws.hcounts ? ws.hcounts + depth0 : nullptr;
     A.hcounts = ws.hcounts;
+    A.win = (A.compact && ws.wave_windows && S_in.lds_geoms > 0) ? PTK_WW : PTK_BLOCK;      // (as launch_shade_trace chose the kernel)
     A.cum_prev = ws.cum_prev; A.cum_out = ws.cum_out; A.cum_stride = ws.cum_stride; A.ring_div = ws.ring_div;
     const bool seg = ws.seg_pref && ws.seg_first && depth0 > 0;
     A.G = Gather{seg ? ws.seg_pref : nullptr, seg ? ws.seg_first : nullptr, nullptr};

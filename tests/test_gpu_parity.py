@@ -233,6 +233,27 @@ def test_batched_ordered_merge(ptk, orc, torch_cuda, monkeypatch, name, res, dep
         assert np.array_equal(img, ref), (batch, int((img != ref).any(axis=1).sum()))
 
 
+@pytest.mark.parametrize("name,res,depth,mode,lanes", [("cornell.txt", (200, 168), 8, "BSDF", 3), ("cornell.txt", (131, 77), 6, "MIS", 1), ("mis_test.txt", (256, 256), 16, "MIS", 3),
+                                                       ("mis_test2.txt", (216, 216), 8, "DIRECT", 1), ("metallic_analytic.txt", (160, 160), 8, "MIS", 3)])
+def test_wave_windows(ptk, orc, torch_cuda, monkeypatch, name, res, depth, mode, lanes):
+    """VERDICT r4 #2b, built in round 5 (opt-in PTK_WAVE_WINDOWS=1; measured slower, profiles/r5_ab_wave_windows.txt): k_shade_trace_w — the fused compact kernel with one
+    wave and one 64-slot window per unit of work, every barrier but two a compiler fence.  Same streams, tables (in units of 64 slots) and keys: radiance and live counts ==
+    oracle, through k_tail's hand-over (open scenes), every sample mode, one and three iterations in flight."""
+    monkeypatch.setenv("PTK_WAVE_WINDOWS", "1")
+    m = MODES[mode]
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    ref = np.zeros((o.P, 3), np.float32); lives = []
+    for it in range(1, 7):
+        lives.append(o.pathtrace(m, it, ref)[1].copy())
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
+    for it in range(1, 7):
+        r.iterate(it)
+        assert np.array_equal(r.live_counts()[0], lives[it - 1]), it
+    img = r.image(); r.close(); s.close()
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+
+
 TS_CASES = [("cornell.txt", (200, 168), 8, "BSDF"), ("cornell.txt", (200, 168), 8, "MIS"), ("cornell.txt", (131, 77), 5, "DIRECT"),
             ("mis_test.txt", (256, 256), 16, "MIS"), ("mis_test.txt", (256, 256), 16, "BSDF"), ("mis_test2.txt", (216, 216), 8, "DIRECT"),
             ("metallic_analytic.txt", (160, 160), 8, "MIS"), ("metallic_analytic.txt", (160, 160), 8, "BSDF"), ("cornell.txt", (24, 24), 8, "BSDF")]
