@@ -737,6 +737,28 @@ def main():
             roofline["frac_timed"] = round(alg / HBM_PEAK_GBS, 4)
             roofline["frac_timed_note"] = "algorithmic bytes of ALL rays of the timed region (224 B per path-bounce) / its wall time / 8 TB/s: the whole pipeline with its overlap, where `frac` is one launch alone on one stream"
             if rec and fused:
+                # The roofline the TIMED configuration actually runs at (rounds 3 and 5): vector-ALU ISSUE.  Vector instructions of one iteration's launches
+                # (committed single-stream PMC pass: SQ_INSTS_VALU per dispatch of k_shade_trace x traceDepth + the camera launch) x 4 cycles per wave64
+                # instruction / (1024 SIMDs x 2.4 GHz) against the timed ms_per_iteration: every figure recomputable from the named files.
+                try:
+                    vi = rec["k_shade_trace"]["counters"]["SQ_INSTS_VALU"] * scene.trace_depth + rec["k_shade_trace_gen"]["counters"]["SQ_INSTS_VALU"]
+                    t_issue_us = vi * 4 / (1024 * 2.4e9) * 1e6
+                    out["valu_issue_timed"] = {"frac": round(t_issue_us / (1e3 * out["ms_per_iteration"]), 4), "bound": "valu",
+                                               "vector_instructions_per_iteration": int(vi), "issue_time_us_per_iteration": round(t_issue_us, 1), "ms_per_iteration": out["ms_per_iteration"],
+                                               "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614 G wave-instructions/s",
+                                               "source": "%s: SQ_INSTS_VALU per dispatch of k_shade_trace x %d + k_shade_trace_gen" % (PMC_FILE, scene.trace_depth),
+                                               "note": "with three iterations in flight the launches' vector instructions fill the SIMDs' issue slots: this, not HBM (frac_timed_measured), bounds the "
+                                                       "timed configuration — which is why removing barriers (k_shade_trace_w: -24 % barrier wait, +27 % instructions, slower), bytes and launches "
+                                                       "(k_trace_shade with its wait) or batching merges did not pay in round 5, and the contracted flavour's -5 % instructions do.  4 cycles per instruction: "
+                                                       "profiles/r3_issue_cost.txt (fma / mul / add 3.1, compares / selects / integer 4.2-4.5, rcp / sqrt 8.2); clock under load not measured (2.4 GHz nominal). "
+                                                       "profiles/%s_pmc_timed.json's lower figure is the SERIALISED pace: rocprofv3 runs one dispatch at a time while it collects counters" % ROUND}
+                    if out["valu_issue_timed"]["frac"] >= 0.8:
+                        roofline["bound_alone"] = roofline["bound"]
+                        roofline["bound"] = "valu"
+                        roofline["bound_note"] = ("TIMED configuration (three iterations in flight): vector-ALU issue, %.2f of its peak (valu_issue_timed).  One launch ALONE on one stream (what frac "
+                                                  "prices): %s" % (out["valu_issue_timed"]["frac"], roofline["bound_note"]))
+                except Exception:
+                    pass
                 per_iter = 0.0
                 for k, mult in (("k_shade_trace", scene.trace_depth), ("k_shade_trace_gen", 1)):
                     t = (rec.get(k) or {}).get("traffic_bytes_per_launch") if isinstance(rec.get(k), dict) else None
