@@ -748,8 +748,8 @@ def main():
                                                "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614 G wave-instructions/s",
                                                "source": "%s: SQ_INSTS_VALU per dispatch of k_shade_trace x %d + k_shade_trace_gen" % (PMC_FILE, scene.trace_depth),
                                                "note": "with three iterations in flight the launches' vector instructions fill the SIMDs' issue slots: this, not HBM (frac_timed_measured), bounds the "
-                                                       "timed configuration — which is why removing barriers (k_shade_trace_w: -24 % barrier wait, +27 % instructions, slower), bytes and launches "
-                                                       "(k_trace_shade with its wait) or batching merges did not pay in round 5, and the contracted flavour's -5 % instructions do.  4 cycles per instruction: "
+                                                       "timed configuration — which is why removing barriers (k_shade_trace_w: -24 %% barrier wait, +27 %% instructions, slower), bytes and launches "
+                                                       "(k_trace_shade with its wait) or batching merges did not pay in round 5, and the contracted flavour's -5 %% instructions do.  4 cycles per instruction: "
                                                        "profiles/r3_issue_cost.txt (fma / mul / add 3.1, compares / selects / integer 4.2-4.5, rcp / sqrt 8.2); clock under load not measured (2.4 GHz nominal). "
                                                        "profiles/%s_pmc_timed.json's lower figure is the SERIALISED pace: rocprofv3 runs one dispatch at a time while it collects counters" % ROUND}
                     if out["valu_issue_timed"]["frac"] >= 0.8:
@@ -757,8 +757,8 @@ def main():
                         roofline["bound"] = "valu"
                         roofline["bound_note"] = ("TIMED configuration (three iterations in flight): vector-ALU issue, %.2f of its peak (valu_issue_timed).  One launch ALONE on one stream (what frac "
                                                   "prices): %s" % (out["valu_issue_timed"]["frac"], roofline["bound_note"]))
-                except Exception:
-                    pass
+                except Exception as e:
+                    out["valu_issue_timed"] = {"error": str(e)[:200]}
                 per_iter = 0.0
                 for k, mult in (("k_shade_trace", scene.trace_depth), ("k_shade_trace_gen", 1)):
                     t = (rec.get(k) or {}).get("traffic_bytes_per_launch") if isinstance(rec.get(k), dict) else None
