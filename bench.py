@@ -543,7 +543,7 @@ def main():
             c = subprocess.run([exe, scene_path, "--mode", a.mode, "--iters", str((a.warmup + a.steps) * IPS), "--warmup", str(a.warmup * IPS), "--no-save",
                                 "--ranks", str(N), "--rank", str(local if N > 1 else 0), "--id-file", idf, "--tile-rows", str(a.tile_rows)]
                                + (["--res", str(res[0]), str(res[1])] if res else []) + (["--depth", str(a.depth)] if a.depth >= 0 else []),
-                               capture_output=True, text=True, timeout=300)
+                               capture_output=True, text=True, timeout=300 if N == 1 else 120)      # (N > 1 has never run on hardware: a communicator that does not come up costs two minutes, not the run)
             j = json.loads([l for l in c.stdout.splitlines() if l.startswith("cpp_rccl ")][-1][len("cpp_rccl "):])
             cpp_rccl = {"value": round(j["rays"] / j["seconds"] / 1e6, 3), "unit": "Mrays/s", "ranks": j["ranks"], "reduce_ms": j["reduce_ms"], "iterations": j["iterations"],
                         "config": "csrc/ptk_headless --ranks N --rank r --id-file F: C++ host, one process per GPU, RCCL (ncclCommInitRank, ncclAllReduce barrier, one "
