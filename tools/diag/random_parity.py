@@ -63,8 +63,11 @@ def one_case(seed, tmp):
     part = (1, 0, 1); spp = 1
     if rng.uniform() < 0.3:
         n = int(rng.integers(2, 5)); part = (n, int(rng.integers(0, n)), int(rng.choice([1, 4, 8]))); spp = int(rng.integers(1, 4))
-    pipeline = int(rng.choice([0, 0, 0, 10, 8, 1] if MESHES else [0, 0, 0, 10, 8]))
+    pipeline = int(rng.choice([0, 0, 0, 10, 8, 1, 11] if MESHES else [0, 0, 0, 10, 8, 11, 11]))      # (11, round 5: k_trace_shade where the scene has no triangles)
     iters = int(rng.integers(3, 13))
+    # round-5 variants that are read when the context is initialised: wave windows (k_shade_trace_w), batched ordered merges, the pooled wide walk
+    knobs = {"PTK_WAVE_WINDOWS": str(int(rng.integers(0, 2))), "PTK_MERGE_BATCH": str(int(rng.choice([1, 1, 2, 3]))), "PTK_WIDE_POOL": str(int(rng.choice([0, 0, 64, 512])))}
+    os.environ.update(knobs)
     s = ptk.Scene(path); o = orc.Scene(path)
     tiles = int(rng.choice([1, 1, 2, 3])) if (lanes == 1 and pipeline in (0, 10) and part[0] == 1) else 1      # tiles in flight: only alone, on the fused launches
     kw = dict(in_flight=lanes, graph=graph or tiles > 1, pipeline=pipeline, tiles=tiles)
@@ -81,7 +84,9 @@ def one_case(seed, tmp):
     ref = acc.img
     img = r.image(); r.close(); s.close(); o.close()
     bad = int((img != ref).any(axis=1).sum())
-    return bad, info, dict(mode=mode, lanes=lanes, tiles=tiles, graph=graph, part=part, spp=spp, pipeline=pipeline, iters=iters, lit=float(ref.sum()))
+    for k in knobs: os.environ.pop(k, None)
+    return bad, info, dict(mode=mode, lanes=lanes, tiles=tiles, graph=graph, part=part, spp=spp, pipeline=pipeline, iters=iters, ww=knobs["PTK_WAVE_WINDOWS"], mb=knobs["PTK_MERGE_BATCH"],
+                           pool=knobs["PTK_WIDE_POOL"], lit=float(ref.sum()))
 
 
 if __name__ == "__main__":
