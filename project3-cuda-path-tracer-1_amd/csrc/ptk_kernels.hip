@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(PTK_BLOCK) k_generate(DevCamera cam, int iter_
 // point and the deferred normal for it (a later round can only lower the key, and then overwrites).
 // WAVE = true (round 5, k_shade_trace_w): the "block" is ONE wave — NT = 64 rays, the lane is the thread index, every array belongs to the wave alone —
 // and a barrier is a compiler fence: a wave's LDS instructions execute in issue order, so a later read of any lane sees the earlier writes of all lanes.
-// (No fence instruction: a fence — even at wavefront scope — makes the compiler drain the vector-memory counter, i.e. wait for the path stores that are
-// meant to overlap the tracing: measured +14 us on the camera launch.  The compiler barrier keeps the program order of the LDS accesses.)
+// (No fence instruction: a fence — even at wavefront scope — may make the compiler drain the vector-memory counter, i.e. wait for the path stores that are
+// meant to overlap the tracing.  The compiler barrier keeps the program order of the LDS accesses; measured: no difference either way.)
 __device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 template <bool WAVE> __device__ __forceinline__ void group_sync() { if (WAVE) wave_sync(); else __syncthreads(); }
 // LDS the block-cooperative closest-hit search works in (24.1 KB for 256 threads)
@@ -1966,14 +1966,15 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
 // ------------------------------------------------------------------------------------------------------------------
 // k_shade_trace_w (round 5) — k_shade_trace's compact layout with WAVE WINDOWS: the unit of work is one wave and its own 64-slot window.
 //
-// Why: by the counters (profiles/r5_pmc_wait.json) a wave of k_shade_trace spends 0.58 of its cycles waiting on data or at a barrier — and the
-// camera launch, which has the same trace phase and barriers but no loads at its head and no shading, still 0.42: most of the wait is the block's
-// ~18 barriers, each of which holds four waves (on four SIMDs, each shared with six other waves) for the slowest of them.  Here a block is four
-// INDEPENDENT waves that share only the staged primitives and materials (one barrier at the start, one at the end for the window bookkeeping):
-// wave w of block b shades hits [64 (4 b + w), + 64) of the previous bounce, keeps its survivors in window 4 b + w of the next buffer, and traces
-// them — every former barrier is a compiler fence (a wave's LDS instructions execute in issue order), the counting sort, the survivor ranks and
-// the inverse map are ballots and lane permutes, the pair list of the closest-hit search is balanced over the wave's 64 lanes.  Same streams,
-// same tables (in units of 64 slots), same keys, same order of additions: bit-identical to k_shade_trace.
+// Why it was built (VERDICT r4 #2b): by the counters (profiles/r5_pmc_wait.json) a wave of k_shade_trace spends 0.58 of its cycles waiting on data or at a
+// barrier — 0.42 even in the camera launch, which has no loads at its head and no shading — and the block has ~18 barriers, each of which holds four waves (on
+// four SIMDs, each shared with six other waves) for the slowest of them.  Here a block is four INDEPENDENT waves that share only the staged primitives and
+// materials (one barrier at the start, one at the end for the window bookkeeping): wave w of block b shades hits [64 (4 b + w), + 64) of the previous bounce,
+// keeps its survivors in window 4 b + w of the next buffer, and traces them — every former barrier is a compiler fence (a wave's LDS instructions execute in
+// issue order), the counting sort, the survivor ranks and the inverse map are ballots and lane permutes, the pair list of the closest-hit search is balanced
+// over the wave's 64 lanes.  Same streams, same tables (in units of 64 slots), same keys, same order of additions: bit-identical to k_shade_trace.
+// What it measured (profiles/r5_ab_wave_windows.txt): the barrier wait does drop (-24 %) and comes back as waiting to ISSUE (+65 %) — the launch is bound by
+// instruction issue, and this form needs 27 % more vector instructions: 19.3 against 21.0 Grays/s.  Opt-in (PTK_WAVE_WINDOWS=1); k_shade_trace stays the default.
 // ------------------------------------------------------------------------------------------------------------------
 #define PTK_WW 64
 template <int MODE, bool GEN>
