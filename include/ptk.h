@@ -256,7 +256,9 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *   11 = (round 5, opt-in) k_trace_shade: a launch TRACES and SHADES one bounce (the first one generates the camera rays), traceDepth launches per
  *       iteration; the hit record never leaves the block, the streams are the reference's PathSegment as three 16-byte records (48 B in, 48 B out per
  *       surviving path-bounce); the compacted slot of a hit path comes from a decoupled look-back over the blocks' hit counts INSIDE the launch
- *       (one tagged 64-bit word per block).  Triangle-free scenes without textures / ENV map; elsewhere it behaves as 8; not with tiles in flight.
+ *       (one tagged 64-bit word per block).  Triangle-free scenes without textures / ENV map; elsewhere it behaves as 8; not with tiles in flight;
+ *       ONE ITERATION AT A TIME only — with several iterations in flight the context renders with 0's kernels: blocks that spin for earlier blocks
+ *       of their launch can starve another launch's blocks of the XCD they need (a hang was observed with four in flight).
  *       Bit-identical; slower than 0 today (every block waits for the slowest earlier block of the launch: 16.7 against 21.3 Grays/s on
  *       cornell.txt; 23.7 if the wait cost nothing — profiles/r5_ab_trace_shade.txt);
  *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the

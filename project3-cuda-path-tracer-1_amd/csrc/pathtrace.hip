@@ -403,12 +403,17 @@ bool sparse_tail() { return g.pipeline != 1 && !g_prof.on &&
                             !(g.lanes.size() && g.lanes[0].ws.stats); }
 // the fused shade + trace launches: pipeline 10 always, pipeline 0 (auto) for triangle-free scenes — with a BVH stage behind every launch
 // the staged kernels are 1-3 % ahead (bunny scene 5.70 vs 5.62 Grays/s); the traversal counters are only kept by the staged kernels
+// ONE ITERATION AT A TIME ONLY.  A block of k_trace_shade spins until every earlier block of its launch has published its hit count.  Alone on the GPU that
+// cannot deadlock: each XCD hands out its share of the workgroups in index order, so the lowest unfinished block is always resident and needs nothing.  Beside
+// OTHER launches whose blocks wait the same way it can: the XCDs dispatch independently, launch A's waiting blocks can fill the XCD that launch B's next block
+// needs and vice versa — observed as a hang with four and more iterations in flight (round 5; the GPU had to be reclaimed).  With several lanes the context
+// therefore renders with the default kernels (bit-identical images either way).
 bool use_ts_pipeline() {
-    return ts_pipeline_wanted(g.pipeline) && !g.tiles && g.scene && trace_shade_usable(dev_view(*g.scene)) && !(g.lanes.size() && g.lanes[0].ws.stats);
+    return ts_pipeline_wanted(g.pipeline) && !g.tiles && g.n_lanes == 1 && g.scene && trace_shade_usable(dev_view(*g.scene)) && !(g.lanes.size() && g.lanes[0].ws.stats);
 }
 bool use_trace_pipeline() {
     if (use_ts_pipeline()) return false;
-    if (!trace_pipeline(g.pipeline) || (g.lanes.size() && g.lanes[0].ws.stats)) return false;
+    if (!(trace_pipeline(g.pipeline) || (g.pipeline == 11 && g.n_lanes > 1)) || (g.lanes.size() && g.lanes[0].ws.stats)) return false;      // (11 with several lanes: the fused default)
     if (g.pipeline == 10 || g.tiles || g.scene->tempDevScene.tri_num == 0 || inline_bvh_choice(g.pipeline)) return true;      // (tiny mesh: walked inside the fused kernel; tiles in flight: only the fused launches carry the bands' cumulative hit counts)
     // larger meshes: a BVH stage follows every launch either way.  The staged kernels are ahead in BSDF / DIRECT (bunny scene 5.93 vs 5.85, 7.8 vs
     // 7.0 Grays/s); in MIS the fused kernel is, since its shadow rays run in a balanced phase at six waves per SIMD (5.69 vs 5.55)

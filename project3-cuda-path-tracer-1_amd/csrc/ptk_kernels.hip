@@ -2188,8 +2188,10 @@ k_shade_trace_w(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ 
 // leaves the block: the block traces its 256 rays, counts its hits, publishes the count and obtains the number of hits in all earlier blocks by
 // a DECOUPLED LOOK-BACK (Merrill & Garland, "Single-pass parallel prefix scan with decoupled look-back", 2016): one 64-bit word per block,
 // {launch tag : 32 | status : 2 | value : 30}; status 1 = the block's own count, 2 = the inclusive prefix; wave 0 inspects 64 predecessors per
-// round and sums counts back to the first inclusive prefix.  A block only ever waits for blocks with a SMALLER index, which the dispatcher
-// started earlier (workgroups are dispatched in index order), so the wait cannot deadlock; the tag (iteration x 256 + bounce + 1, unique per
+// round and sums counts back to the first inclusive prefix.  A block only ever waits for blocks with a SMALLER index; each XCD hands out its share of
+// the workgroups in index order, so with the GPU to itself the lowest unfinished block of a launch is always resident and the wait cannot deadlock.
+// Beside other launches that wait the same way it CAN (the XCDs dispatch independently: two launches can fill the XCDs each other's next block needs —
+// observed as a hang with four iterations in flight), so the render loop uses this kernel with one iteration at a time only (pathtrace.hip); the tag (iteration x 256 + bounce + 1, unique per
 // launch of a lane) makes stale words of earlier launches invisible without a clear.  (Rounds 1-2 tried the CHAINED form — every block waits for
 // its predecessor's prefix, pipeline 3 — and lost: 11 ns x 2 500 blocks in series.  Look-back has no chain: a block adds up counts that are
 // published before any prefix is.)

@@ -263,9 +263,10 @@ TS_CASES = [("cornell.txt", (200, 168), 8, "BSDF"), ("cornell.txt", (200, 168), 
 def test_trace_shade_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
     """Round 5, pipeline 11 — k_trace_shade: a launch TRACES and SHADES one bounce, the hit record never leaves the block, and the reference's RNG
     key (the compacted slot of a hit path, pathtrace.cu:458,532) comes from a decoupled look-back over the blocks' hit counts inside the launch.
-    Radiance, per-bounce live counts and the ray total == the oracle, bit for bit: one iteration at a time and three in flight with graph replay
-    (ordered accumulation), closed and open scenes (mis_test: the sparse tail takes over), every sample mode, frames that are not a multiple of
-    the window size."""
+    Radiance, per-bounce live counts and the ray total == the oracle, bit for bit: closed and open scenes (mis_test: the sparse tail takes over), every
+    sample mode, frames that are not a multiple of the window size.  The kernel runs with ONE iteration at a time only (its blocks spin for the earlier
+    blocks of their launch, which is deadlock-free only while no other launch waits beside it — pathtrace.hip: use_ts_pipeline); with three in flight
+    the context renders with the default kernels, which the second pass checks."""
     m = MODES[mode]
     o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
     ref = np.zeros((o.P, 3), np.float32); lives = []; rays = 0
@@ -292,17 +293,17 @@ def test_trace_shade_pipeline_full_size_and_sharded(ptk, orc, torch_cuda):
     out = {}
     for pipeline in (0, 11):
         s = ptk.Scene(os.path.join(SC, "cornell.txt"))
-        r = ptk.Renderer(s, MODES["BSDF"], pipeline=pipeline, in_flight=3, graph=True)
+        r = ptk.Renderer(s, MODES["BSDF"], pipeline=pipeline, in_flight=1, graph=True)
         for it in range(1, 13):
             r.iterate(it)
         out[pipeline] = (r.image(), r.live_counts()[0].copy(), r.ray_total()); r.close(); s.close()
     assert out[0][2] == out[11][2] and np.array_equal(out[0][1], out[11][1]) and np.array_equal(out[0][0], out[11][0])
-    W, H, D, SPP, LANES = 96, 80, 5, 2, 2
+    W, H, D, SPP, LANES = 96, 80, 5, 2, 1
     o = orc.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
     for part in (0, 1):
         acc = orc.Accumulator(o.P, LANES, SPP, MODES["MIS"])
         s = ptk.Scene(os.path.join(SC, "cornell.txt"), res=(W, H), depth=D)
-        r = ptk.Renderer(s, MODES["MIS"], partition=(2, part, 8), pipeline=11, in_flight=LANES, graph=True, spp=SPP)
+        r = ptk.Renderer(s, MODES["MIS"], partition=(2, part, 8), pipeline=11, in_flight=LANES, graph=False, spp=SPP)
         for step in range(1, 6):
             r.iterate(step); acc.batch(o, MODES["MIS"], step, partition=(2, part, 8))
         img = r.image(); r.close(); s.close()
