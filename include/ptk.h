@@ -36,6 +36,7 @@ extern "C" {
 #define PTK_E_NOSCENE  1002
 #define PTK_E_PARSE    1003
 #define PTK_E_NODEVICE 1004
+#define PTK_E_DEVICE   1005   /* a kernel gave a device-side wait up (pipeline 11 only: its look-back, see ptk_set_pipeline); the image is not valid */
 
 /* enum SampleMode { BSDF, DirectLi, MIS } — src/preview.h:13 */
 enum { PTK_MODE_BSDF = 0, PTK_MODE_DIRECTLI = 1, PTK_MODE_MIS = 2 };
@@ -259,8 +260,10 @@ int ptk_partition_pixel(int W, int n_parts, int part, int tile_rows, int j);
  *       (one tagged 64-bit word per block).  Triangle-free scenes without textures / ENV map; elsewhere it behaves as 8; not with tiles in flight;
  *       ONE ITERATION AT A TIME only — with several iterations in flight the context renders with 0's kernels: blocks that spin for earlier blocks
  *       of their launch can starve another launch's blocks of the XCD they need (a hang was observed with four in flight).
- *       Bit-identical; slower than 0 today (every block waits for the slowest earlier block of the launch: 16.7 against 21.3 Grays/s on
- *       cornell.txt; 23.7 if the wait cost nothing — profiles/r5_ab_trace_shade.txt);
+ *       The wait is bounded (PTK_LB_POLL_LIMIT looks, default 2^20): a block that gives up lets the launch drain and the next read of the
+ *       image returns PTK_E_DEVICE — what two processes sharing one GPU with this pipeline may get instead of a hung GPU.
+ *       Bit-identical; slower than 0 today (every block waits for the slowest earlier block of the launch: 11.4 against 12.2 Grays/s on
+ *       cornell.txt one iteration at a time; three in flight, before the restriction: 16.7 / 21.3, 23.7 if the wait cost nothing — profiles/r5_ab_trace_shade.txt);
  *   7 / 8 = staged (the default until round 3): per bounce an intersect stage, shading with block-local compaction of the
  *       survivors, and the window prefix in a separate one-block k_segments launch (7) or in the last block of the shading kernel (8);
  *   1 = like 7, the BVH is walked inside the intersect kernel for every ray, one ray per lane (no k_tail);

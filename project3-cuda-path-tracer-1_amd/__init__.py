@@ -32,7 +32,7 @@ SCENES = os.path.join(REPO_ROOT, "scenes")
 MODE_BSDF, MODE_DIRECTLI, MODE_MIS = 0, 1, 2
 GEOM_SPHERE, GEOM_CUBE, GEOM_OBJ = 0, 1, 2
 MAT_LAMBERTIAN, MAT_METALLIC, MAT_DIELECTRIC, MAT_MICROFACET, MAT_LIGHT = 0, 1, 2, 3, 4
-E_BADARG, E_NOSCENE, E_PARSE, E_NODEVICE = 1001, 1002, 1003, 1004
+E_BADARG, E_NOSCENE, E_PARSE, E_NODEVICE, E_DEVICE = 1001, 1002, 1003, 1004, 1005
 
 # every symbol include/ptk.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [

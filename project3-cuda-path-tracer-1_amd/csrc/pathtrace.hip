@@ -284,6 +284,8 @@ int lane_init(Lane& l, int idx) {
     // cleared again by every launch's last block)
     if ((rc = dalloc(&l.ws.look, 2 * blocks + 64))) return rc;
     if ((e = hipMemsetAsync(l.ws.look, 0, sizeof(unsigned long long) * (2 * blocks + 64), l.stream)) != hipSuccess) return (int)e;
+    l.ws.look_gave_up = l.ws.look + (2 * blocks + 63);            // (the last word of the table: raised by a block that gives its wait up)
+    if (const char* v = std::getenv("PTK_LB_POLL_LIMIT")) l.ws.look_limit = std::max(0, std::atoi(v));      // (tests: 0 = never wait)
     const size_t n_done = 32 * ((size_t)blocks / 32 + 3);          // top counter + one per 32 blocks, each on its own 128-B line (segments_tail)
     if ((rc = dalloc(&l.seg_done_mem, n_done))) return rc;
     if ((e = hipMemsetAsync(l.seg_done_mem, 0, sizeof(int) * n_done, l.stream)) != hipSuccess) return (int)e;
@@ -733,8 +735,22 @@ int image_reader_enqueued() {
     return 0;
 }
 
+// pipeline 11: did a block of k_trace_shade give its look-back wait up (ptk_kernels.hip: LookBack)?  Called where the host has just waited for the
+// lanes anyway; the image is wrong then, and the caller gets PTK_E_DEVICE instead of it.
+int lookback_status() {
+    if (!ts_pipeline_wanted(g.pipeline)) return 0;
+    for (Lane& l : g.lanes) {
+        if (!l.ws.look_gave_up) continue;
+        unsigned long long w = 0;
+        const hipError_t e = hipMemcpy(&w, l.ws.look_gave_up, sizeof w, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return (int)e;
+        if (w) return PTK_E_DEVICE;
+    }
+    return 0;
+}
+
 [[noreturn]] void die(const char* msg, int rc, const char* file, int line) {      // checkCUDAErrorFn, scene.cpp:20-38
-    std::fprintf(stderr, "HIP error (%s:%d): %s: %s\n", file, line, msg, rc >= 1000 ? "ptk argument/scene error" : hipGetErrorString((hipError_t)rc));
+    std::fprintf(stderr, "HIP error (%s:%d): %s: %s\n", file, line, msg, rc == PTK_E_DEVICE ? "a kernel gave a device-side wait up (pipeline 11)" : rc >= 1000 ? "ptk argument/scene error" : hipGetErrorString((hipError_t)rc));
     std::exit(EXIT_FAILURE);
 }
 #define PTK_CHECK(msg, expr) do { int _rc = (expr); if (_rc) die(msg, _rc, __FILE__, __LINE__); } while (0)
@@ -817,7 +833,8 @@ int ptk_get_image(float* host_out) {
     if (rc) return rc;
     hipError_t e = hipMemcpyAsync(host_out, g.image, sizeof(float) * 3 * (size_t)g.P, hipMemcpyDeviceToHost, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
-    return rc_of(hipStreamSynchronize(g.lanes[0].stream));
+    if ((rc = rc_of(hipStreamSynchronize(g.lanes[0].stream)))) return rc;
+    return lookback_status();
 }
 int ptk_get_image_device(float** out) {
     if (!g.live) return PTK_E_NOSCENE;
@@ -826,7 +843,7 @@ int ptk_get_image_device(float** out) {
     if (rc) return rc;
     if ((rc = rc_of(hipStreamSynchronize(g.lanes[0].stream)))) return rc;
     *out = g.image;
-    return 0;
+    return lookback_status();
 }
 int ptk_copy_image_to_device(float* dst) {
     if (!g.live) return PTK_E_NOSCENE;
@@ -991,7 +1008,7 @@ int ptk_get_traversal_stats(unsigned long long* out2) {
     }
     return 0;
 }
-int ptk_stream_sync(void) { if (!g.live) return PTK_E_NOSCENE; sync_all(); return 0; }
+int ptk_stream_sync(void) { if (!g.live) return PTK_E_NOSCENE; sync_all(); return lookback_status(); }
 int ptk_timer_start(void) {
     if (!g.live) return PTK_E_NOSCENE;
     sync_all();

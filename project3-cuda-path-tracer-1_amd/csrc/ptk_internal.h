@@ -83,6 +83,8 @@ struct Workspace {               // per-render-context scratch, device memory
     const int* cum_prev = nullptr; int* cum_out = nullptr; int cum_stride = 0, ring_div = 1;
     int wide_lpr = 4;            // lanes per ray of the wide walk (4 or 2; ptk_kernels.hip k_traverse_wide)
     unsigned long long* look = nullptr;      // pipeline 11 (k_trace_shade): one look-back word per block of a launch [blocks + 1]
+    unsigned long long* look_gave_up = nullptr;   // ... and the word a block raises when it gives the wait up (ptk_kernels.hip: LookBack); look_limit: polls before that
+    int look_limit = 1 << 20;
     bool wave_windows = false;   // fused pipeline, compact streams: k_shade_trace_w — one wave and one 64-slot window per unit of work (window tables in units of 64)
     int wide_pool = 0;           // > 0: the wide walk pools that many work-list rays per block (k_traverse_pool); 0: one ray per lane group (k_traverse_wide)
     int walk = PTK_WALK_THREADED; // how the work-list rays are walked (PTK_WALK_THREADED / PTK_WALK_WIDE; AUTO is resolved by the render loop)

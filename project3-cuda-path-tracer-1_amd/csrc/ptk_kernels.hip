@@ -2213,7 +2213,12 @@ k_shade_trace_w(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ 
 #ifndef PTK_LB_SPAN
 #define PTK_LB_SPAN 4
 #endif
-struct LookBack { unsigned long long* words; };       // [blocks + 1] per lane
+// EXIT CONDITION of the wait: a block that has looked PTK look-back `limit` times at a predecessor that still has not published gives up — it raises
+// *gave_up, takes the missing counts as zero and publishes an inclusive prefix, so that no later block waits for it.  The launch then drains with wrong
+// keys and the host reports PTK_E_DEVICE at its next read (pathtrace.hip: lookback_status).  A legitimate wait is bounded by the duration of the launch
+// (< 1 ms); the default limit is about a second of polling.  This turns the cross-launch deadlock described at k_trace_shade (two processes sharing a
+// GPU, say) from a hung GPU into an error.
+struct LookBack { unsigned long long* words; unsigned long long* gave_up; int limit; };       // words: [blocks + 1] per lane
 __device__ __forceinline__ unsigned long long lb_word(unsigned tag, unsigned status, unsigned value) { return ((unsigned long long)tag << 32) | ((unsigned long long)status << 30) | value; }
 // lane 0 of a wave of block b, as soon as the block's count is known (block 0: that is its inclusive prefix already)
 __device__ __forceinline__ void lookback_publish(const LookBack& lb, unsigned tag, int b, int count) {
@@ -2222,7 +2227,7 @@ __device__ __forceinline__ void lookback_publish(const LookBack& lb, unsigned ta
 // wave 0 of block b (b > 0 or not): the number of hits in blocks [0, b); publishes the block's inclusive prefix
 __device__ __forceinline__ int lookback_exclusive(const LookBack& lb, unsigned tag, int b, int count, int lane) {
     if (b == 0) return 0;
-    int excl = 0;
+    int excl = 0, polls = 0;
     for (int j = b - 1; ; ) {
         unsigned long long w[PTK_LB_SPAN];
         unsigned st[PTK_LB_SPAN];
@@ -2240,7 +2245,11 @@ __device__ __forceinline__ int lookback_exclusive(const LookBack& lb, unsigned t
             if (incl) first_incl = 64 * k + __builtin_ctzll(incl);
             if (missing) first_missing = 64 * k + __builtin_ctzll(missing);
         }
-        if (first_missing < first_incl) { __builtin_amdgcn_s_sleep(4); continue; }      // a predecessor this round needs has not published yet
+        if (first_missing < first_incl) {                         // a predecessor this round needs has not published yet
+            if (polls++ < lb.limit) { __builtin_amdgcn_s_sleep(4); continue; }
+            if (lane == 0) atomicOr(lb.gave_up, 1ull);            // (wave-uniform: the ballots above are)
+            break;
+        }
         int v = 0;
 #pragma unroll
         for (int k = 0; k < PTK_LB_SPAN; ++k) v += (64 * k + lane <= first_incl) ? (int)((unsigned)w[k] & 0x3fffffffu) : 0;
@@ -3075,7 +3084,7 @@ static int launch_trace_shade_t(const SceneView& S, const GenArgs& G, int iter, 
 int launch_trace_shade(const SceneView& S_in, int mode, const ::Camera& cam, int n_parts, int part, int tile_rows, int n_pix, int trace_depth,
                        int iter, int depth, int capacity, PtkPaths cur, PtkPaths nxt, float* img, const Workspace& ws, hipStream_t st, bool last, void (*mark)(int, bool)) {
     if (grid_for(capacity) == 0) return 0;
-    if (!ws.seg_pref || !ws.seg_first || !ws.agg_b || !ws.seg_done || !ws.look || !trace_shade_usable(S_in)) return PTK_E_BADARG;
+    if (!ws.seg_pref || !ws.seg_first || !ws.agg_b || !ws.seg_done || !ws.look || !ws.look_gave_up || !trace_shade_usable(S_in)) return PTK_E_BADARG;
     SceneView S = S_in;
     S.slim_hits = 1;
     const bool gen = depth == 0;
@@ -3091,7 +3100,7 @@ int launch_trace_shade(const SceneView& S_in, int mode, const ::Camera& cam, int
     const int* d_n = gen ? nullptr : ws.counts + depth;
     const SegTail tail = {ws.seg_done, ws.seg_pref, ws.seg_first, ws.counts + depth + 1, last ? ws.iter_dev : nullptr, ws.iter_stride};
     const int sbias = ws.slot_bias + (depth >= 1 ? ws.dbg_shift_deep : ws.dbg_shift0);
-    const LookBack lb = {ws.look};
+    const LookBack lb = {ws.look, ws.look_gave_up, ws.look_limit};
     const int cap = gen ? n_pix * ws.spp : capacity;
     mark(gen ? 0 : 2, true);
     int rc;

@@ -286,6 +286,30 @@ def test_trace_shade_pipeline(ptk, orc, torch_cuda, name, res, depth, mode):
         assert not bad.any(), f"lanes {lanes}: {int(bad.sum())} of {len(ref)} pixels differ; first {np.argwhere(bad)[:3].ravel()}"
 
 
+def test_trace_shade_wait_has_an_exit(ptk, torch_cuda):
+    """k_trace_shade's look-back is a wait inside a launch; every wave must reach an exit whatever happens beside it (another process on the GPU
+    running the same pipeline could hold the slots its predecessors need).  PTK_LB_POLL_LIMIT=0 makes a block give up at its first unanswered look:
+    the launch drains, and the next read reports PTK_E_DEVICE instead of an image.  (Child process: the limit is read when the context is set up.)"""
+    import subprocess
+    import sys
+    code = (
+        "import importlib, os, sys; sys.path.insert(0, %r); import torch; torch.cuda.set_device(0)\n"
+        "ptk = importlib.import_module('project3-cuda-path-tracer-1_amd')\n"
+        "s = ptk.Scene(%r); r = ptk.Renderer(s, 0, pipeline=11, in_flight=1, graph=False)\n"
+        "codes = []\n"
+        "for it in range(1, 5):\n"
+        "    r.iterate(it)\n"
+        "    try: r.image(); codes.append(0)\n"
+        "    except ptk.PtkError as e: codes.append(e.code)\n"
+        "print('codes', codes)\n" % (ROOT, os.path.join(SC, "cornell.txt")))
+    env = dict(os.environ, PTK_LB_POLL_LIMIT="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("codes")][-1]
+    assert str(ptk.E_DEVICE) in line, line                         # 2 500 blocks per launch: some block looks before a predecessor has published
+    # (with the default limit the same renders read back fine: test_trace_shade_pipeline)
+
+
 def test_trace_shade_pipeline_full_size_and_sharded(ptk, orc, torch_cuda):
     """the same at BASELINE configs[1]'s size (2 500 blocks per launch: 40 rounds of look-back for the last block) against the default pipeline's
     image — itself checked against the oracle at this size by test_benchmarked_configuration_full_size — and under the tile partition with
