@@ -238,10 +238,10 @@ def roofline_of(scene, prof, rays_p, counts, nodes, tris, rays_s, steps, scene_f
     hbm = {"achieved_hbm": round(traffic / (avg_us * 1e-6) / 1e9, 1), "frac_hbm": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
            "achieved_hbm_note": "PMC traffic / this run's average launch time: the rate the HBM really sees (node / triangle re-reads of a "
                                 "BVH scene are served by L2); `achieved` is the ALGORITHMIC rate at the reference's struct sizes (SURVEY 8d)"} if traffic else {}
+    b_ctr, b_note = bound_from_counters((pmc or {}).get("counters"), traffic, rp_us or avg_us)
     return {
-        "bound": "valu" if not has_bvh else "valu+latency",
-        "bound_note": "priced against the HBM roofline as the contract asks, but NOT bound by it: PMC traffic ~= the algorithmic bytes and the kernel sits at "
-                      "~0.2 of 8 TB/s because it needs ~14 VALU instructions per byte; see roofline_valu and DESIGN.md section 5",
+        "bound": b_ctr,
+        "bound_note": b_note + ("  (~14 vector instructions per byte moved: see roofline_valu; the walk of a BVH scene adds the dependent chain of its slowest rays, DESIGN.md section 5.2)"),
         "kernel": "k_intersect (the staged pipeline 8's intersection kernel, the kernel SURVEY 8d's 76 B/ray is defined on)" + (" + k_list + k_traverse_wide + k_finalize (the intersect stage)" if has_bvh else ""),
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_measured": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None, "traffic": traffic,
@@ -360,8 +360,8 @@ def roofline_valu(scene_file, roof):
     rate = c["SQ_INSTS_VALU"] / (roof["avg_launch_us"] * 1e-6)
     return {"achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
             "insts_valu_per_launch": c["SQ_INSTS_VALU"], "kernel": roof.get("kernel"),
-            "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the pipeline's instructions "
-                    "fill the issue slots (valu_busy_timed, from counters of the timed configuration).  Peak = 1024 SIMDs x 2.4 GHz nominal / 4; packed instructions counted once; what an instruction really costs: profiles/r3_issue_cost.txt"}
+            "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the issue slots are still not what the pipeline "
+                    "is short of (valu_issue_timed.issue_sensitivity).  Peak = 1024 SIMDs x 2.4 GHz nominal / 4; packed instructions counted once; what an instruction really costs: profiles/r3_issue_cost.txt"}
 
 
 def main():
@@ -737,26 +737,41 @@ def main():
             roofline["frac_timed"] = round(alg / HBM_PEAK_GBS, 4)
             roofline["frac_timed_note"] = "algorithmic bytes of ALL rays of the timed region (224 B per path-bounce) / its wall time / 8 TB/s: the whole pipeline with its overlap, where `frac` is one launch alone on one stream"
             if rec and fused:
-                # The roofline the TIMED configuration actually runs at (rounds 3 and 5): vector-ALU ISSUE.  Vector instructions of one iteration's launches
-                # (committed single-stream PMC pass: SQ_INSTS_VALU per dispatch of k_shade_trace x traceDepth + the camera launch) x 4 cycles per wave64
-                # instruction / (1024 SIMDs x 2.4 GHz) against the timed ms_per_iteration: every figure recomputable from the named files.
+                # How close the TIMED configuration is to vector-ALU ISSUE (rounds 3 and 5).  Vector instructions of one iteration's launches (committed
+                # single-stream PMC pass: SQ_INSTS_VALU per dispatch of k_shade_trace x traceDepth + the camera launch) x cycles per wave64 instruction /
+                # (1024 SIMDs x 2.4 GHz) against the timed ms_per_iteration — 0.94 at a flat 4 cycles, 0.73 at the 3.1 an fma / mul / add was measured at —
+                # AND the direct experiment (tools/diag/issue_sensitivity.sh, profiles/<round>_issue_sensitivity.json): diagnostic builds with 10 / 19 / 39 %
+                # more vector instructions (pure fma chains) run 0.9 / 4.2 / 10.9 % longer, the contracted flavour's 5 % fewer buy nothing.  An issue-bound
+                # pipeline would pay for every added instruction; this one pays 0.14-0.39 of their issue time: the SIMDs have idle issue slots, what the timed
+                # configuration is short of is wave slots x wave lifetime (seven blocks per CU, each a serial chain of dependent loads, barriers and its own
+                # ~1 600 vector instructions).  Every figure recomputable from the named files.
                 try:
                     vi = rec["k_shade_trace"]["counters"]["SQ_INSTS_VALU"] * scene.trace_depth + rec["k_shade_trace_gen"]["counters"]["SQ_INSTS_VALU"]
                     t_issue_us = vi * 4 / (1024 * 2.4e9) * 1e6
-                    out["valu_issue_timed"] = {"frac": round(t_issue_us / (1e3 * out["ms_per_iteration"]), 4), "bound": "valu",
+                    sens = None
+                    try:
+                        sj = json.load(open(os.path.join(ROOT, "profiles", "%s_issue_sensitivity.json" % ROUND)))
+                        sens = {k: {f: {q: r[q] for q in ("instructions", "time", "paid_share_of_issue_time") if q in r} for f, r in sj[k].items() if f != "exact"} for k in ("timed", "one_at_a_time") if k in sj}
+                        sens["source"] = "profiles/%s_issue_sensitivity.json (tools/diag/issue_sensitivity.sh: diagnostic builds, alternating child processes)" % ROUND
+                    except Exception:
+                        pass
+                    out["valu_issue_timed"] = {"frac": round(t_issue_us / (1e3 * out["ms_per_iteration"]), 4), "frac_at_measured_fma_cost": round(t_issue_us * 3.1 / 4 / (1e3 * out["ms_per_iteration"]), 4),
+                                               "bound": "not issue: wave slots x wave lifetime (see issue_sensitivity)",
                                                "vector_instructions_per_iteration": int(vi), "issue_time_us_per_iteration": round(t_issue_us, 1), "ms_per_iteration": out["ms_per_iteration"],
-                                               "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614 G wave-instructions/s",
+                                               "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614 G wave-instructions/s (frac); / 3.1 cycles, what v_fma / v_mul / v_add_f32 cost "
+                                                       "in profiles/r3_issue_cost.txt (frac_at_measured_fma_cost)",
                                                "source": "%s: SQ_INSTS_VALU per dispatch of k_shade_trace x %d + k_shade_trace_gen" % (PMC_FILE, scene.trace_depth),
-                                               "note": "with three iterations in flight the launches' vector instructions fill the SIMDs' issue slots: this, not HBM (frac_timed_measured), bounds the "
-                                                       "timed configuration — which is why removing barriers (k_shade_trace_w: -24 %% barrier wait, +27 %% instructions, slower), bytes and launches "
-                                                       "(k_trace_shade with its wait) or batching merges did not pay in round 5, and the contracted flavour's -5 %% instructions do.  4 cycles per instruction: "
-                                                       "profiles/r3_issue_cost.txt (fma / mul / add 3.1, compares / selects / integer 4.2-4.5, rcp / sqrt 8.2); clock under load not measured (2.4 GHz nominal). "
-                                                       "profiles/%s_pmc_timed.json's lower figure is the SERIALISED pace: rocprofv3 runs one dispatch at a time while it collects counters" % ROUND}
-                    if out["valu_issue_timed"]["frac"] >= 0.8:
-                        roofline["bound_alone"] = roofline["bound"]
-                        roofline["bound"] = "valu"
-                        roofline["bound_note"] = ("TIMED configuration (three iterations in flight): vector-ALU issue, %.2f of its peak (valu_issue_timed).  One launch ALONE on one stream (what frac "
-                                                  "prices): %s" % (out["valu_issue_timed"]["frac"], roofline["bound_note"]))
+                                               "issue_sensitivity": sens,
+                                               "note": "the instruction count priced at a flat cost says 0.73-0.94 of the issue slots; the direct experiment says the slots are NOT what the timed "
+                                                       "configuration is short of: +10 / +19 / +39 %% vector instructions (fma chains, no memory) cost +0.9 / +4.2 / +10.9 %% time — 0.14-0.39 of the added issue "
+                                                       "time, where an issue-bound pipeline pays all of it — and the contracted flavour's -5 %% instructions buy nothing (issue_sensitivity).  The limit is "
+                                                       "occupancy x latency: seven blocks per CU (72 VGPRs, 22 KB of LDS), each a serial chain — four dependent load round trips at its head, 18 barriers, its "
+                                                       "own instruction stream — so what pays is a shorter chain (k_trace_shade with a free prefix: +11 / +21 %%; instruction scheduling for memory clauses: "
+                                                       "+2-5 %%) or another wave slot (5 -> 6 -> 7 waves per SIMD: +8 %%, +6 %%), not fewer instructions or bytes.  profiles/%s_pmc_timed.json's figure is the "
+                                                       "SERIALISED pace: rocprofv3 runs one dispatch at a time while it collects counters" % ROUND}
+                    roofline["bound_timed"] = "latency"
+                    roofline["bound_note"] = ("TIMED configuration (three iterations in flight): neither HBM (frac_timed_measured) nor vector-ALU issue (valu_issue_timed.issue_sensitivity) is "
+                                              "saturated — wave slots x wave lifetime.  One launch ALONE on one stream (what frac prices): %s" % roofline["bound_note"])
                 except Exception as e:
                     out["valu_issue_timed"] = {"error": str(e)[:200]}
                 per_iter = 0.0

@@ -124,6 +124,10 @@ int  ptk_scene_bvh_device_bytes(const PtkScene* s, unsigned long long* out4);
  * used), leaf records, levels, per-ray stack bound.  nodes: 144 B each, leaves: 64 B each (layout: csrc/ptk_device.hpp). */
 int  ptk_scene_wide_bvh_counts(const PtkScene* s, int* counts);
 int  ptk_scene_get_wide_bvh(const PtkScene* s, void* nodes, void* leaves);
+/* ... and of the 16-wide variant the environment variable PTK_WIDE_WIDTH=16 makes ptk_scene_upload build instead (round 5: built, bit-identical, slower —
+ * DESIGN.md section 5.2): width = 8 or 16; nodes of 144 B / 272 B. */
+int  ptk_scene_wide_bvh_counts_w(const PtkScene* s, int width, int* counts);
+int  ptk_scene_get_wide_bvh_w(const PtkScene* s, int width, void* nodes, void* leaves);
 /* Upload the scene tables to the current HIP device (DevScene::initiate, src/scene.cpp:569-663). */
 int  ptk_scene_upload(PtkScene* s);
 

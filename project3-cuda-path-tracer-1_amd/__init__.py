@@ -38,7 +38,7 @@ E_BADARG, E_NOSCENE, E_PARSE, E_NODEVICE, E_DEVICE = 1001, 1002, 1003, 1004, 100
 ABI_SYMBOLS = [
     "ptk_scene_load", "ptk_scene_free", "ptk_scene_error", "ptk_scene_counts", "ptk_scene_get_camera",
     "ptk_scene_get_geoms", "ptk_scene_get_materials", "ptk_scene_get_triangles", "ptk_scene_get_bvh",
-    "ptk_scene_get_lights", "ptk_scene_bvh_device_bytes", "ptk_scene_wide_bvh_counts", "ptk_scene_get_wide_bvh", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
+    "ptk_scene_get_lights", "ptk_scene_bvh_device_bytes", "ptk_scene_wide_bvh_counts", "ptk_scene_get_wide_bvh", "ptk_scene_wide_bvh_counts_w", "ptk_scene_get_wide_bvh_w", "ptk_scene_get_texture_size", "ptk_scene_get_texture", "ptk_scene_upload", "ptk_generate_rays", "ptk_intersect", "ptk_compact",
     "ptk_shade", "ptk_tonemap", "ptk_pathtrace_init", "ptk_pathtrace_free", "ptk_pathtrace",
     "ptk_set_sample_mode", "ptk_get_sample_mode", "ptk_get_image", "ptk_get_image_device",
     "ptk_copy_image_to_device", "ptk_get_live_counts", "ptk_get_ray_total", "ptk_set_tile_partition",
@@ -122,6 +122,8 @@ def _load() -> C.CDLL:
     lib.ptk_scene_wide_bvh_counts.argtypes = [vp, vp]
     lib.ptk_scene_bvh_device_bytes.argtypes = [vp, vp]
     lib.ptk_scene_get_wide_bvh.argtypes = [vp, vp, vp]
+    lib.ptk_scene_wide_bvh_counts_w.argtypes = [vp, C.c_int, vp]
+    lib.ptk_scene_get_wide_bvh_w.argtypes = [vp, C.c_int, vp, vp]
     lib.ptk_scene_get_texture_size.argtypes = [vp, ci, vp, vp]
     lib.ptk_scene_get_texture.argtypes = [vp, ci, vp]
     lib.ptk_generate_rays.argtypes = [C.POINTER(PtkCamera), ci, ci, PtkPaths, vp]
@@ -199,13 +201,13 @@ class Scene:
     def bvh(self): return self._table(lib.ptk_scene_get_bvh, BVHNODE_DT, 6 * self.bvh_size)
     def lights(self): return self._table(lib.ptk_scene_get_lights, LIGHT_DT, self.n_lights)
 
-    def wide_bvh(self):
-        """-> (nodes uint32 [n, 36], leaves (WIDE_LEAF_DT) [m], depth, stack bound) of the 8-wide collapsed tree; n = 0 if there is none"""
+    def wide_bvh(self, width: int = 8):
+        """-> (nodes uint32 [n, 36 | 68], leaves (WIDE_LEAF_DT) [m], depth, stack bound) of the 8-wide (or 16-wide) collapsed tree; n = 0 if there is none"""
         c = np.zeros(4, np.int32)
-        _chk(lib.ptk_scene_wide_bvh_counts(self.handle, c.ctypes.data), "ptk_scene_wide_bvh_counts")
-        nodes = np.zeros((int(c[0]), 36), np.uint32); leaves = np.zeros(int(c[1]), WIDE_LEAF_DT)
+        _chk(lib.ptk_scene_wide_bvh_counts_w(self.handle, width, c.ctypes.data), "ptk_scene_wide_bvh_counts_w")
+        nodes = np.zeros((int(c[0]), 4 + 4 * width), np.uint32); leaves = np.zeros(int(c[1]), WIDE_LEAF_DT)
         if c[0] > 0:
-            _chk(lib.ptk_scene_get_wide_bvh(self.handle, nodes.ctypes.data, leaves.ctypes.data), "ptk_scene_get_wide_bvh")
+            _chk(lib.ptk_scene_get_wide_bvh_w(self.handle, width, nodes.ctypes.data, leaves.ctypes.data), "ptk_scene_get_wide_bvh_w")
         return nodes, leaves, int(c[2]), int(c[3])
 
     def bvh_device_bytes(self):

@@ -166,10 +166,12 @@ int DevScene::initiate(Scene& scene) {
     wide_nodes = wide_depth = wide_stack = 0;
     if (!scene.triangles.empty()) {                          // 8-wide collapsed form of the same tree (wide_bvh.h)
         WideBvh wb;
-        if (build_wide_bvh(scene.gpuBVHNodes, B, scene.triangles, wb)) {
-            if ((rc = upload(&dev_wnodes, wb.nodes))) return rc;
+        const char* ww = getenv("PTK_WIDE_WIDTH");
+        wide_width = (ww && atoi(ww) == 16) ? 16 : 8;
+        if (build_wide_bvh(scene.gpuBVHNodes, B, scene.triangles, wb, wide_width)) {
+            if ((rc = wide_width == 16 ? upload(&dev_wnodes, wb.nodes16) : upload(&dev_wnodes, wb.nodes))) return rc;
             if ((rc = upload(&dev_wleaves, wb.leaves))) return rc;
-            wide_nodes = (int)wb.nodes.size(); wide_depth = wb.depth; wide_stack = wb.max_stack;
+            wide_nodes = (int)(wb.nodes.size() + wb.nodes16.size()); wide_depth = wb.depth; wide_stack = wb.max_stack;
         }
     }
     tri_num = (int)tv.size(); bvh_size = B;
@@ -360,23 +362,26 @@ int ptk_scene_get_bvh(const PtkScene* s, PtkBvhNode* o) {
     return 0;
 }
 
-int ptk_scene_wide_bvh_counts(const PtkScene* s, int* c) {
-    if (!s || !s->scene || !c) return PTK_E_BADARG;
+int ptk_scene_wide_bvh_counts_w(const PtkScene* s, int width, int* c) {
+    if (!s || !s->scene || !c || (width != 8 && width != 16)) return PTK_E_BADARG;
     c[0] = c[1] = c[2] = c[3] = 0;
     WideBvh wb;
-    if (!s->scene->triangles.empty() && build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb)) {
-        c[0] = (int)wb.nodes.size(); c[1] = (int)wb.leaves.size(); c[2] = wb.depth; c[3] = wb.max_stack;
+    if (!s->scene->triangles.empty() && build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb, width)) {
+        c[0] = (int)(wb.nodes.size() + wb.nodes16.size()); c[1] = (int)wb.leaves.size(); c[2] = wb.depth; c[3] = wb.max_stack;
     }
     return 0;
 }
-int ptk_scene_get_wide_bvh(const PtkScene* s, void* nodes, void* leaves) {
-    if (!s || !s->scene || !nodes || !leaves) return PTK_E_BADARG;
+int ptk_scene_get_wide_bvh_w(const PtkScene* s, int width, void* nodes, void* leaves) {
+    if (!s || !s->scene || !nodes || !leaves || (width != 8 && width != 16)) return PTK_E_BADARG;
     WideBvh wb;
-    if (s->scene->triangles.empty() || !build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb)) return PTK_E_BADARG;
-    std::memcpy(nodes, wb.nodes.data(), wb.nodes.size() * sizeof(WideNodeHost));
+    if (s->scene->triangles.empty() || !build_wide_bvh(s->scene->gpuBVHNodes, s->scene->bvhSize, s->scene->triangles, wb, width)) return PTK_E_BADARG;
+    if (width == 16) std::memcpy(nodes, wb.nodes16.data(), wb.nodes16.size() * sizeof(WideNode16Host));
+    else std::memcpy(nodes, wb.nodes.data(), wb.nodes.size() * sizeof(WideNodeHost));
     std::memcpy(leaves, wb.leaves.data(), wb.leaves.size() * sizeof(WideLeafHost));
     return 0;
 }
+int ptk_scene_wide_bvh_counts(const PtkScene* s, int* c) { return ptk_scene_wide_bvh_counts_w(s, 8, c); }
+int ptk_scene_get_wide_bvh(const PtkScene* s, void* nodes, void* leaves) { return ptk_scene_get_wide_bvh_w(s, 8, nodes, leaves); }
 
 int ptk_scene_bvh_device_bytes(const PtkScene* s, unsigned long long* out4) {
     if (!s || !s->scene || !out4) return PTK_E_BADARG;

@@ -285,6 +285,9 @@ struct DevNode {
 //              the child spans [p + qlo * 2^e, p + qhi * 2^e] (a superset of its exact box; unused slots are inverted);
 //              before[d] = mask of the children a ray of direction tree d (pathtrace.cu:242-244) visits before this one;
 //              ref = wide-node index, or 0x80000000 | leaf-record index.
+// 16-wide variant (round 5, PTK_WIDE_WIDTH=16; SceneView::wide_width), 272 B = 17 x uint4: the same header (n = 1..16) and sixteen child records whose
+// bytes 6..8 hold pos[0..5], four bits each — the child's POSITION in direction d's visiting order — instead of the before masks: a hit child's rank among
+// the hit children is the number of hit children at smaller positions (the group ORs 1 << pos of its hit children into one 16-bit word).
 // Leaf record, 64 B = 4 x uint4: exact fp32 box of the reference's leaf node, the triangle in edge form (as DevTriE), its index.
 struct WideLeaf { float lo[3], hi[3], v0[3], e1[3], e2[3]; int tri; };
 struct DevTriE { float v0[3], e1[3], e2[3], pad[3]; };                          // 48 B: v0 and the two edges (e = v - v0 as in Bounds3.hpp:300-301)
@@ -304,6 +307,7 @@ struct SceneView {
     const uint32_t* ranks;       // [6][n_tris] with one copy: rank of triangle t in direction d's leaf order (ranks[d * n_tris + t]); null with six
     const DevTriE* trie;         // traversal form of the triangles
     const uint4* wnodes;         int n_wnodes;   // 8-wide collapsed form of the same tree (WideNode, 9 x uint4 = 144 B each); null = none
+    int wide_width;              // 8, or 16: the 16-wide variant (17 x uint4 per node)
     const uint4* wleaves;        // WideLeaf records (4 x uint4 each), children of one wide node consecutive
     const DevTriV* triv;         const DevTriA* tria; int n_tris;
     const DevLight* lights;      int n_lights;

@@ -32,7 +32,7 @@ inline SceneView dev_view(const ::Scene& s) {
     d.nodes = (const DevNode*)t.dev_nodes;       d.bvh_size = t.bvh_size;
     d.n_copies = t.n_copies;                     d.ranks = (const uint32_t*)t.dev_ranks;
     d.trie = (const DevTriE*)t.dev_trie;
-    d.wnodes = (const uint4*)t.dev_wnodes;       d.n_wnodes = t.wide_nodes;
+    d.wnodes = (const uint4*)t.dev_wnodes;       d.n_wnodes = t.wide_nodes;  d.wide_width = t.wide_width;
     d.wleaves = (const uint4*)t.dev_wleaves;
     d.triv = (const DevTriV*)t.dev_triv;         d.tria = (const DevTriA*)t.dev_tria; d.n_tris = t.tri_num;
     d.lights = (const DevLight*)t.dev_lights;    d.n_lights = (int)s.lights.size();

@@ -681,18 +681,22 @@ __device__ __forceinline__ int wide_leaf_visit(const uint4 l0, const uint4 l1, c
 #ifndef PTK_WIDE_BLOCK
 #define PTK_WIDE_BLOCK 256
 #endif
-template <bool STATS, int LPR>       // LPR lanes per ray (4: shortest chain; 2: fewer instructions per ray, see the header comment)
+// W (round 5): children per node — 8, or the 16-wide variant (PTK_WIDE_WIDTH=16; ptk_device.hpp): 17 x uint4 per node, a hit child's place on the stack from
+// the positions of the hit children in the ray's visiting order instead of the before masks; everything else is the same walk.
+__device__ __forceinline__ unsigned wide_pos16(const uint4 c, int dir) { return (((c.y >> 16) | (c.z << 16)) >> (4 * dir)) & 15u; }
+template <bool STATS, int LPR, int W = 8>       // LPR lanes per ray (4: shortest chain; 2: fewer instructions per ray, see the header comment)
 __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, unsigned long long* stats,
                                                               const int* __restrict__ srcidx, int stats_mode = 0) {
-    constexpr int RAYS = PTK_WIDE_BLOCK / LPR, NCH = 8 / LPR;     // rays per block; children per lane
-    __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
+    static_assert(W == 8 || (W == 16 && (LPR == 2 || LPR == 4)), "16-wide nodes: two or four lanes per ray");
+    constexpr int RAYS = PTK_WIDE_BLOCK / LPR, NCH = W / LPR, U4 = W + 1;     // rays per block; children per lane; uint4 per node
+    __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * U4];
     __shared__ unsigned s_stack[RAYS * PTK_WIDE_STRIDE];
     const int m = (int)*list_count;
     if (blockIdx.x * RAYS >= m) return;
     const int n_top = S.n_wnodes < PTK_WIDE_TOP ? S.n_wnodes : PTK_WIDE_TOP;
     if (PTK_WIDE_TOP > 0) {
-        for (int k = threadIdx.x; k < n_top * 9; k += PTK_WIDE_BLOCK) s_top[k] = S.wnodes[k];
+        for (int k = threadIdx.x; k < n_top * U4; k += PTK_WIDE_BLOCK) s_top[k] = S.wnodes[k];
         __syncthreads();
     }
     const int q = threadIdx.x & (LPR - 1);                       // lane within the ray's group
@@ -722,16 +726,27 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
                 if (!(cur & PTK_WIDE_LEAF)) {
                     uint4 q0, ch[NCH];                           // lane q owns children q, q + LPR, ...
                     if (PTK_WIDE_TOP > 0 && (int)cur < n_top) {
-                        const uint4* np = s_top + cur * 9; q0 = np[0];
+                        const uint4* np = s_top + cur * U4; q0 = np[0];
 #pragma unroll
                         for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
                         asm volatile("" : "+v"(q0.x), "+v"(ch[0].x));
                     } else {
-                        const uint4* np = S.wnodes + (size_t)cur * 9; q0 = np[0];
+                        const uint4* np = S.wnodes + (size_t)cur * U4; q0 = np[0];
 #pragma unroll
                         for (int k = 0; k < NCH; ++k) ch[k] = np[1 + q + LPR * k];
                         asm volatile("" : "+v"(q0.x), "+v"(ch[0].x));
                     }
+#ifdef PTK_DIAG_PAD_WALK      // timing experiment only (tools/diag/issue_sensitivity.sh): N more fma per node visit on live registers, same results
+                    {
+                        float p0 = r.o.x, p1 = r.o.y, p2 = r.d.x, p3 = r.d.y;
+#pragma unroll
+                        for (int i = 0; i < PTK_DIAG_PAD_WALK / 4; ++i) {
+                            p0 = __builtin_fmaf(p0, p1, p2); p1 = __builtin_fmaf(p1, p2, p3); p2 = __builtin_fmaf(p2, p3, p0); p3 = __builtin_fmaf(p3, p0, p1);
+                            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                        }
+                        asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+                    }
+#endif
                     if (STATS) nv += (q == 0);
                     const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
                     f.Ax = sx * r.inv.x; f.Ay = sy * r.inv.y; f.Az = sz * r.inv.z;                     // exact (power-of-two scale)
@@ -745,11 +760,13 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
                     f.Bnx = Bx - mx; f.Bfx = Bx + mx; f.Bny = By - my; f.Bfy = By + my; f.Bnz = Bz - mz; f.Bfz = Bz + mz;
                     const int nc = (int)(q0.w >> 24);
                     bool hit[NCH];
-                    unsigned H = 0u;                              // hit children of this ray (bit = child index)
+                    unsigned pos[NCH];                            // (W = 16) the child's position in the ray's visiting order
+                    unsigned H = 0u;                              // hit children of this ray (bit = child index; W = 16: bit = position in the visiting order)
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
                         hit[k] = (q + LPR * k < nc) & wide_child_test(ch[k], f, r.t_min);      // no short circuit: straight-line code
-                        if (LPR == 2 || LPR == 4) H |= hit[k] ? (1u << (q + LPR * k)) : 0u;    // own bits; the group's lanes are ORed below
+                        if (W == 16) { pos[k] = wide_pos16(ch[k], r.dir); H |= hit[k] ? (1u << pos[k]) : 0u; }
+                        else if (LPR == 2 || LPR == 4) H |= hit[k] ? (1u << (q + LPR * k)) : 0u;    // own bits; the group's lanes are ORed below
                         else {
                             const unsigned long long bal = __ballot(hit[k]);
                             H |= ((unsigned)(bal >> qsh) & ((1u << LPR) - 1u)) << (LPR * k);
@@ -775,7 +792,7 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
                     // all hit children at once, in reverse visiting order: the child visited first ends on top
 #pragma unroll
                     for (int k = 0; k < NCH; ++k)
-                        if (hit[k]) stk[sp + nh - 1 - __popc(H & wide_before(ch[k], r.dir))] = ch[k].w;
+                        if (hit[k]) stk[sp + nh - 1 - __popc(H & (W == 16 ? (1u << pos[k]) - 1u : wide_before(ch[k], r.dir)))] = ch[k].w;
                     sp += nh;
                 } else {
                     const uint4* lp = S.wleaves + (size_t)(cur & ~PTK_WIDE_LEAF) * 4;
@@ -1863,6 +1880,17 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             const float4 o4 = s_ray[tid], d4 = s_ray[NT + tid]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
         }
         Analytic a;
+#ifdef PTK_DIAG_PAD_VALU     // timing experiment only (tools/diag/issue_sensitivity.sh): N more vector instructions per wave — four independent fma chains on live
+        {                        // registers, no memory, no LDS — to read how the launch's time answers to its instruction count.  Same results.
+            float p0 = ro.x, p1 = ro.y, p2 = rd.x, p3 = rd.y;
+#pragma unroll
+            for (int i = 0; i < PTK_DIAG_PAD_VALU / 4; ++i) {
+                p0 = __builtin_fmaf(p0, p1, p2); p1 = __builtin_fmaf(p1, p2, p3); p2 = __builtin_fmaf(p2, p3, p0); p3 = __builtin_fmaf(p3, p0, p1);
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            }
+            asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+        }
+#endif
         if (gs.on) analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
         else { a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0); if (active) analytic_closest(S, gs, ro, rd, a); }
         if (!GEN) PTK_PHASE(0);                      // 4: (shadow phase +) closest hit: candidates, pair list, exact tests
@@ -2803,11 +2831,16 @@ inline int grid_for(int n) { return (n + PTK_BLOCK - 1) / PTK_BLOCK; }
 // per block; 0: k_traverse_wide, one ray per group of lpr lanes.  Bit-identical hits either way (pick_wide_pool below chooses).
 static void launch_wide_walk(const SceneView& S, int g, int lpr, int pool, const unsigned* queue, const int* list, PtkPaths paths, PtkHits hits, int* valid,
                              const int* srcidx, hipStream_t st) {
-    if (pool > 0) {
+    if (pool > 0 && S.wide_width == 8) {             // (the pooled walk exists for 8-wide nodes only)
         const int blocks = (g * PTK_BLOCK + pool - 1) / pool;
         const size_t lds = (size_t)pool * 2 * sizeof(float4);
         if (lpr == 2) k_traverse_pool<2><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
         else k_traverse_pool<4><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
+        return;
+    }
+    if (S.wide_width == 16) {
+        if (lpr == 2) k_traverse_wide<false, 2, 16><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, paths, hits, valid, nullptr, srcidx);
+        else k_traverse_wide<false, 4, 16><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, paths, hits, valid, nullptr, srcidx);
         return;
     }
     if (lpr == 2) k_traverse_wide<false, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, paths, hits, valid, nullptr, srcidx);
@@ -2947,7 +2980,9 @@ int launch_intersect_stage(const SceneView& S, int n, const int* d_n, PtkPaths c
     const bool wide = walk == PTK_WALK_WIDE && S.wnodes;
     k_list<<<g, PTK_BLOCK, 0, st>>>(n, d_n, hflag, hagg, list, queue, 0);
     rc = launch_rc(); if (rc) { mark(1, false); return rc; }
-    if (wide && stats && wide_stats && wide_lpr == 2) k_traverse_wide<true, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
+    if (wide && stats && wide_stats && S.wide_width == 16 && wide_lpr == 2) k_traverse_wide<true, 2, 16><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
+    else if (wide && stats && wide_stats && S.wide_width == 16) k_traverse_wide<true, 4, 16><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
+    else if (wide && stats && wide_stats && wide_lpr == 2) k_traverse_wide<true, 2><<<2 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
     else if (wide && stats && wide_stats) k_traverse_wide<true, 4><<<4 * g * (PTK_BLOCK / PTK_WIDE_BLOCK), PTK_WIDE_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src, wide_stats_mode);
     else if (wide && !stats) launch_wide_walk(S, g, wide_lpr, wide_pool, queue, list, cur, hits, valid, G.src, st);
     else if (stats) k_traverse<true><<<g, PTK_BLOCK, 0, st>>>(S, queue, list, cur, hits, valid, stats, G.src);

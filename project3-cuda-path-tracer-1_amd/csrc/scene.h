@@ -112,6 +112,7 @@ public:
     void* dev_wnodes = nullptr;       // 8-wide collapsed tree (wide_bvh.h), 144 B = 9 x uint4 per node; null if the tree could not be collapsed
     void* dev_wleaves = nullptr;      // its leaf records, 64 B each
     int wide_nodes = 0, wide_depth = 0, wide_stack = 0;
+    int wide_width = 8;               // children per wide node: 8, or 16 with PTK_WIDE_WIDTH=16 (272-B nodes)
     void* dev_triv = nullptr;         // ptk::DevTriV[]
     void* dev_tria = nullptr;         // ptk::DevTriA[]
     void* dev_lights = nullptr;       // ptk::DevLight[]

@@ -67,46 +67,51 @@ int collapse_mode() { const char* e = std::getenv("PTK_WIDE_COLLAPSE"); return (
 
 struct CollapsePlan {
     bool on = false;
-    std::vector<double> open;        // [B][9]: cost of subtree i OPENED into <= k slots (k = 2..8; its two children share them), non-increasing in k
+    int W = 8, K = 9;                // children per wide node (8 or 16); row length W + 1
+    std::vector<double> open;        // [B][K]: cost of subtree i OPENED into <= k slots (k = 2..W; its two children share them), non-increasing in k
     std::vector<double> node;        // [B]: cost of subtree i as a wide node of its own (behind one slot); 0 for a leaf
-    std::vector<uint8_t> split;      // [B][9]: slots given to the left child when i is opened into exactly k
-    void solve(const Topo& T, double node_bias) {
-        open.assign((size_t)T.B * 9, 0.0); node.assign(T.B, 0.0); split.assign((size_t)T.B * 9, 0);
-        auto slots = [&](int i, int k) { return T.leaf(i) ? 0.0 : (k == 1 ? node[i] : std::min(node[i], open[(size_t)i * 9 + k])); };
+    std::vector<uint8_t> split;      // [B][K]: slots given to the left child when i is opened into exactly k
+    void solve(const Topo& T, double node_bias, int width) {
+        W = width; K = W + 1;
+        open.assign((size_t)T.B * K, 0.0); node.assign(T.B, 0.0); split.assign((size_t)T.B * K, 0);
+        auto slots = [&](int i, int k) { return T.leaf(i) ? 0.0 : (k == 1 ? node[i] : std::min(node[i], open[(size_t)i * K + k])); };
         for (int i = T.B - 1; i >= 0; --i) {                 // preorder array: children come later
             if (T.leaf(i)) continue;
             const int L = T.left(i), R = T.right(i);
-            double* o = &open[(size_t)i * 9]; uint8_t* sp = &split[(size_t)i * 9];
-            for (int k = 2; k <= 8; ++k) {
+            double* o = &open[(size_t)i * K]; uint8_t* sp = &split[(size_t)i * K];
+            for (int k = 2; k <= W; ++k) {
                 double best = 1e300; int bj = 1;
                 for (int j = 1; j < k; ++j) { const double c = slots(L, j) + slots(R, k - j); if (c < best) { best = c; bj = j; } }
                 if (k > 2 && o[k - 1] <= best) { o[k] = o[k - 1]; sp[k] = 0; }       // 0: no better than with one slot less — use that plan
                 else { o[k] = best; sp[k] = (uint8_t)bj; }
             }
-            node[i] = T.area(i) + node_bias + o[8];
+            node[i] = T.area(i) + node_bias + o[W];
         }
         on = true;
     }
     void expand(const Topo& T, int i, int k, bool forced, std::vector<int>& fr) const {
-        if (T.leaf(i) || k == 1 || (!forced && node[i] <= open[(size_t)i * 9 + k])) { fr.push_back(i); return; }
-        while (split[(size_t)i * 9 + k] == 0) --k;
-        const int j = split[(size_t)i * 9 + k];
+        if (T.leaf(i) || k == 1 || (!forced && node[i] <= open[(size_t)i * K + k])) { fr.push_back(i); return; }
+        while (split[(size_t)i * K + k] == 0) --k;
+        const int j = split[(size_t)i * K + k];
         expand(T, T.left(i), j, false, fr); expand(T, T.right(i), k - j, false, fr);
     }
-    void cut(const Topo& T, int r, std::vector<int>& fr) const { expand(T, r, 8, true, fr); }
+    void cut(const Topo& T, int r, std::vector<int>& fr) const { expand(T, r, W, true, fr); }
 };
 
 } // namespace
 
-bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<Triangle>& tris, WideBvh& out) {
+bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<Triangle>& tris, WideBvh& out, int width) {
     out = WideBvh();
+    if (width != 8 && width != 16) return false;
+    const int W = width;
+    out.width = W;
     Topo T{mt, B};
     if (tris.empty() || !check_topology(T)) return false;
     struct Pending { int root; int level; };
     std::deque<Pending> queue;
     queue.push_back({0, 0});
     CollapsePlan plan;
-    if (collapse_mode() != 0) { const char* e = std::getenv("PTK_WIDE_NODE_BIAS"); plan.solve(T, (e ? std::atof(e) : 0.0) * T.area(0)); }
+    if (collapse_mode() != 0) { const char* e = std::getenv("PTK_WIDE_NODE_BIAS"); plan.solve(T, (e ? std::atof(e) : 0.0) * T.area(0), W); }
     std::vector<int> slot_of(B, -1);
     std::vector<int> node_root;                      // binary root of every wide node (for the stack bound)
     std::vector<std::vector<int>> kids;              // inner children (wide indices) per wide node
@@ -121,7 +126,7 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
         else if (plan.on) plan.cut(T, r, fr);
         else {
             fr.push_back(T.left(r)); fr.push_back(T.right(r));
-            while (fr.size() < 8) {
+            while ((int)fr.size() < W) {
                 int best = -1; double ba = -1.0;
                 for (size_t k = 0; k < fr.size(); ++k) if (!T.leaf(fr[k]) && T.area(fr[k]) > ba) { ba = T.area(fr[k]); best = (int)k; }
                 if (best < 0) break;
@@ -131,13 +136,13 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
             }
         }
         const int n = (int)fr.size();
-        WideNodeHost nd; std::memset(&nd, 0, sizeof(nd));
+        uint32_t ndw[68]; std::memset(ndw, 0, sizeof(ndw));      // 9 (W = 8) or 17 (W = 16) uint4
         const GpuBVHNode& box = mt[r];
         uint32_t imask = 0;
         for (int c = 0; c < n; ++c) if (!T.leaf(fr[c])) imask |= 1u << c;
         // quantisation frame: origin = box.pMin, per-axis scale 2^e with p + 255 * 2^e >= box.pMax
         uint32_t eb[3];
-        uint8_t qlo[3][8], qhi[3][8];
+        uint8_t qlo[3][16], qhi[3][16];
         for (int a = 0; a < 3; ++a) {
             const long double p = comp(box.pMin, a), hi = comp(box.pMax, a);
             if (!std::isfinite((double)p) || !std::isfinite((double)hi)) return false;
@@ -149,7 +154,7 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
                                                                       // plane that would cull a child wrongly) only for e <= 20; larger extents (> 2.7e8 units) -> threaded walk
             eb[a] = (uint32_t)(e + 127);
             const long double s = std::ldexp(1.0L, e);
-            for (int c = 0; c < 8; ++c) { qlo[a][c] = 255; qhi[a][c] = 0; }
+            for (int c = 0; c < W; ++c) { qlo[a][c] = 255; qhi[a][c] = 0; }
             for (int c = 0; c < n; ++c) {
                 const long double lo_c = comp(mt[fr[c]].pMin, a), hi_c = comp(mt[fr[c]].pMax, a);
                 long double ql = std::floor((lo_c - p) / s), qh = std::ceil((hi_c - p) / s);
@@ -161,10 +166,10 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
             }
         }
         float pf[3] = {box.pMin.x, box.pMin.y, box.pMin.z};
-        std::memcpy(&nd.w[0], pf, 12);
-        nd.w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)n << 24);
+        std::memcpy(&ndw[0], pf, 12);
+        ndw[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)n << 24);
         // children: inner ones become consecutive wide nodes (breadth-first), leaves consecutive leaf records (slot order)
-        uint32_t ref[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t ref[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         std::vector<int> my_kids;
         for (int c = 0; c < n; ++c) {
             if (imask & (1u << c)) { queue.push_back({fr[c], cur.level + 1}); my_kids.push_back((int)next_index); ref[c] = (uint32_t)next_index; ++next_index; }
@@ -185,31 +190,39 @@ bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<
             }
         }
         // visiting order per direction -> before[d][c]: the children visited before child c by a ray of direction tree d
-        uint32_t before[6][8];
+        // (W = 16: pos[d][c], the child's POSITION in direction d's visiting order, four bits each — a set of sixteen children per direction would not
+        // fit the 16-byte child record; the kernel ranks a hit child by the hit children at smaller positions)
+        uint32_t before[6][16], pos[6][16];
         for (int c = 0; c < n; ++c) slot_of[fr[c]] = c;
         for (int d = 0; d < 6; ++d) {
             std::vector<int> ord;
             order_slots(T, d, r, slot_of, ord);
             if ((int)ord.size() != n) return false;
             uint32_t seen = 0;
-            for (int k = 0; k < n; ++k) { before[d][ord[k]] = seen; seen |= 1u << ord[k]; }
-            for (int c = n; c < 8; ++c) before[d][c] = 0;
+            for (int k = 0; k < n; ++k) { before[d][ord[k]] = seen; pos[d][ord[k]] = (uint32_t)k; seen |= 1u << ord[k]; }
+            for (int c = n; c < W; ++c) { before[d][c] = 0; pos[d][c] = 0; }
         }
         for (int c = 0; c < n; ++c) slot_of[fr[c]] = -1;
-        for (int c = 0; c < 8; ++c) {
-            uint32_t* w = &nd.w[4 + 4 * c];
+        for (int c = 0; c < W; ++c) {
+            uint32_t* w = &ndw[4 + 4 * c];
             w[0] = (uint32_t)qlo[0][c] | ((uint32_t)qlo[1][c] << 8) | ((uint32_t)qlo[2][c] << 16) | ((uint32_t)qhi[0][c] << 24);
-            w[1] = (uint32_t)qhi[1][c] | ((uint32_t)qhi[2][c] << 8) | (before[0][c] << 16) | (before[1][c] << 24);
-            w[2] = before[2][c] | (before[3][c] << 8) | (before[4][c] << 16) | (before[5][c] << 24);
+            if (W == 8) {
+                w[1] = (uint32_t)qhi[1][c] | ((uint32_t)qhi[2][c] << 8) | (before[0][c] << 16) | (before[1][c] << 24);
+                w[2] = before[2][c] | (before[3][c] << 8) | (before[4][c] << 16) | (before[5][c] << 24);
+            } else {
+                w[1] = (uint32_t)qhi[1][c] | ((uint32_t)qhi[2][c] << 8) | (pos[0][c] << 16) | (pos[1][c] << 20) | (pos[2][c] << 24) | (pos[3][c] << 28);
+                w[2] = pos[4][c] | (pos[5][c] << 4);
+            }
             w[3] = ref[c];
         }
-        out.nodes.push_back(nd);
+        if (W == 8) { WideNodeHost nd; std::memcpy(nd.w, ndw, sizeof(nd.w)); out.nodes.push_back(nd); }
+        else { WideNode16Host nd; std::memcpy(nd.w, ndw, sizeof(nd.w)); out.nodes16.push_back(nd); }
         kids.push_back(my_kids); nkids.push_back(n);
     }
-    if (out.leaves.size() != tris.size() || out.nodes.size() != next_index) return false;
+    if (out.leaves.size() != tris.size() || out.nodes.size() + out.nodes16.size() != next_index) return false;
     // per-ray stack bound: a visit pushes at most (children - 1) entries and descends into one
-    std::vector<int> need(out.nodes.size(), 0);
-    for (int i = (int)out.nodes.size() - 1; i >= 0; --i) {
+    std::vector<int> need(next_index, 0);
+    for (int i = (int)next_index - 1; i >= 0; --i) {
         int below = 0;
         for (int k : kids[i]) below = std::max(below, need[k]);
         need[i] = (nkids[i] - 1) + below;

@@ -20,10 +20,13 @@
 namespace ptk {
 
 struct WideNodeHost { uint32_t w[36]; };                 // 144 B = 9 x uint4, see ptk_device.hpp
+struct WideNode16Host { uint32_t w[68]; };               // 272 B = 17 x uint4: the 16-wide variant (round 5, PTK_WIDE_WIDTH=16), see ptk_device.hpp
 struct WideLeafHost { float lo[3], hi[3], v0[3], e1[3], e2[3]; int tri; };   // 64 B
 
 struct WideBvh {
     std::vector<WideNodeHost> nodes;                     // breadth-first: the top levels are the first entries
+    std::vector<WideNode16Host> nodes16;                 // ... or these, when built with width 16 (exactly one of the two is filled)
+    int width = 8;
     std::vector<WideLeafHost> leaves;                    // children of one node are consecutive
     int depth = 0;                                       // levels of wide nodes
     int max_stack = 0;                                   // upper bound of the per-ray stack the traversal kernel needs
@@ -33,6 +36,6 @@ struct WideBvh {
 // mt: the 6 * B direction-ordered nodes of Scene::gpuBVHNodes (preorder, same boxes in every copy).  Returns false (and
 // leaves `out.ok` false) if the table is not a preorder binary tree with one triangle per leaf; callers then keep the
 // threaded walk.
-bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<Triangle>& tris, WideBvh& out);
+bool build_wide_bvh(const std::vector<GpuBVHNode>& mt, int B, const std::vector<Triangle>& tris, WideBvh& out, int width = 8);
 
 } // namespace ptk

@@ -383,6 +383,32 @@ def test_pooled_walk_equals_one_ray_per_group(ptk, orc, torch_cuda, monkeypatch,
             assert np.array_equal(img, ref), (pool, lanes, int((img != ref).any(axis=1).sum()))
 
 
+@pytest.mark.parametrize("mode,pipeline", [("BSDF", 0), ("MIS", 0), ("BSDF", 6)])
+def test_sixteen_wide_nodes(ptk, orc, torch_cuda, monkeypatch, mode, pipeline):
+    """Round 5 (second half): the 16-wide variant of the collapsed tree (PTK_WIDE_WIDTH=16: 1 103 nodes of 272 B for the bunny, fill 10.1,
+    six levels; a hit child's place on the stack from its position in the ray's visiting order).  Any frontier of the same binary tree walked in the
+    reference's leaf order is parity-preserving (csrc/wide_bvh.h): radiance and live counts == the oracle, two and four lanes per ray, one and three
+    iterations in flight.  (Built, bit-identical and slower than the 8-wide tree: profiles/r5_ab_wide16.txt — the default stays 8.)"""
+    path = os.path.join(SC, "bunny_cornell.txt")
+    res, depth = (200, 168), 6
+    o = orc.Scene(path, res=res, depth=depth)
+    ref = np.zeros((o.P, 3), np.float32); lives = []
+    for it in (1, 2, 3, 4):
+        lives.append(o.pathtrace(MODES[mode], it, ref)[1].copy())
+    monkeypatch.setenv("PTK_WIDE_WIDTH", "16")
+    for lpr in ("2", "4"):
+        monkeypatch.setenv("PTK_WIDE_LPR", lpr)          # (read once per process: whichever comes first holds — the lanes below cover both group sizes anyway)
+        for lanes in (1, 3):
+            s = ptk.Scene(path, res=res, depth=depth)
+            r = ptk.Renderer(s, MODES[mode], pipeline=pipeline, in_flight=lanes, graph=lanes > 1)
+            got = []
+            for it in (1, 2, 3, 4):
+                r.iterate(it); got.append(r.live_counts()[0].copy())
+            img = r.image(); r.close(); s.close()
+            assert np.array_equal(np.stack(got), np.stack(lives)), (lpr, lanes)
+            assert np.array_equal(img, ref), (lpr, lanes, int((img != ref).any(axis=1).sum()))
+
+
 def test_pooled_walk_is_the_choice_at_2048(ptk, torch_cuda, monkeypatch):
     out = {}
     for pool in (None, "0"):

@@ -18,22 +18,32 @@ LEAF = 0x80000000
 
 
 def _children(node):
-    """-> list of (qlo[3], qhi[3], before[6], ref) of the n children of a 36-word node"""
+    """-> list of (qlo[3], qhi[3], before[6], ref) of the n children of a 36-word (8-wide) or 68-word (16-wide) node.  The 16-wide node stores the
+    child's POSITION in each direction's visiting order (four bits each); `before` is rebuilt from the positions of its siblings."""
     n = int(node[3] >> 24)
-    out = []
+    out, pos = [], []
     for c in range(n):
         w0, w1, w2, ref = (int(x) for x in node[4 + 4 * c: 8 + 4 * c])
         qlo = (w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255)
         qhi = (w0 >> 24, w1 & 255, (w1 >> 8) & 255)
-        before = ((w1 >> 16) & 255, w1 >> 24, w2 & 255, (w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24)
+        if len(node) == 36:
+            before = ((w1 >> 16) & 255, w1 >> 24, w2 & 255, (w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24)
+        else:
+            bits = (w1 >> 16) | ((w2 & 255) << 16)
+            pos.append(tuple((bits >> (4 * d)) & 15 for d in range(6)))
+            before = None
         out.append((qlo, qhi, before, ref))
+    if pos:
+        for d in range(6): assert sorted(p[d] for p in pos) == list(range(n)), "positions are a permutation"
+        out = [(qlo, qhi, tuple(sum(1 << k for k in range(n) if pos[k][d] < pos[c][d]) for d in range(6)), ref) for c, (qlo, qhi, _, ref) in enumerate(out)]
     return out
 
 
+@pytest.mark.parametrize("width", [8, 16])
 @pytest.mark.parametrize("name", ["bunny_cornell.txt", "obj_test.txt"])
-def test_wide_bvh_structure(ptk, name):
+def test_wide_bvh_structure(ptk, name, width):
     s = ptk.Scene(os.path.join(SC, name))
-    nodes, leaves, depth, stack = s.wide_bvh()
+    nodes, leaves, depth, stack = s.wide_bvh(width)
     tris = s.triangles(); bvh = s.bvh(); B = s.bvh_size
     assert len(nodes) > 0 and len(leaves) == s.n_triangles and depth >= 1
     # 1. leaves: a permutation of the triangles, exact boxes and edge forms
@@ -48,7 +58,7 @@ def test_wide_bvh_structure(ptk, name):
     need = np.zeros(len(nodes), np.int64)
     for i in range(len(nodes) - 1, -1, -1):
         ch = _children(nodes[i])
-        assert 1 <= len(ch) <= 8
+        assert 1 <= len(ch) <= width
         p = nodes[i][:3].view(np.float32)
         scale = [np.array([((int(nodes[i][3]) >> (8 * a)) & 255) << 23], np.uint32).view(np.float32)[0] for a in range(3)]
         blo, bhi, below = [], [], 0
