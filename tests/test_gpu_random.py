@@ -1,7 +1,7 @@
 """Randomised parity (tools/diag/random_parity.py: seeded random scenes — open and closed rooms, rotated overlapping cubes / spheres, all
 five material types, sphere / cube / triangle lights, OBJ meshes of 12 / 320 / 10 000 triangles — in a random mode, resolution, depth, with
 random iterations in flight, graph replay, tile partition, samples per launch and pipeline): image and live counts == the CPU oracle bit
-for bit.  The sweeps recorded in profiles/r3_random_parity.txt ran 1 470 seeds; this keeps a slice of them in the GPU tier."""
+for bit.  The sweeps recorded in profiles/r3_random_parity.txt ran 1 470 seeds (r5: 9 000 more, profiles/r5_random_parity.txt); this keeps a slice of them in the GPU tier."""
 import importlib.util
 import os
 import sys
@@ -42,4 +42,4 @@ def test_random_scenes_equal_the_oracle(ptk, orc, torch_cuda, tmp_path, meshes, 
         bad, info, cfg = m.one_case(seed, str(tmp_path))
         assert bad == 0, (seed, info, cfg, bad)
         lit += cfg["lit"] > 0
-    assert lit >= n // 3          # the generator must keep producing scenes that are not black
+    assert lit >= 3 * n // 4      # the generator must keep producing scenes that are not black (round 5: its room holds the camera; ~90 % lit)
