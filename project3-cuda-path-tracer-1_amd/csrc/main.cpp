@@ -74,7 +74,8 @@ static bool writePNG(const std::string& path, int W, int H, const unsigned char*
 #define RCCL_CHECK(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { std::fprintf(stderr, "RCCL error (%s:%d): %s: %s\n", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); std::exit(EXIT_FAILURE); } } while (0)
 #define HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::fprintf(stderr, "HIP error (%s:%d): %s: %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); std::exit(EXIT_FAILURE); } } while (0)
 
-// the ncclUniqueId through a file: rank 0 writes PATH.tmp and renames it (atomic), the others wait for PATH (at most 120 s)
+// the ncclUniqueId through a file: rank 0 writes PATH.tmp and renames it (atomic), the others wait for PATH (at most 120 s); rank 0 removes PATH once the
+// communicator exists.  PATH must not exist when the job starts (a file left by a job that died would be read as this job's id).
 static void exchange_id(ncclUniqueId& id, int rank, const std::string& path) {
     if (rank == 0) {
         RCCL_CHECK(ncclGetUniqueId(&id));
@@ -178,6 +179,7 @@ int main(int argc, char** argv) {
         ncclUniqueId id;
         exchange_id(id, rank, id_file);
         RCCL_CHECK(ncclCommInitRank(&comm, ranks, id, rank));
+        if (rank == 0) std::remove(id_file.c_str());      // every rank has read it (the init is collective): a later job that reuses PATH must not find this id
         HIP_CHECK(hipStreamCreateWithFlags(&cst, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void**)&sync_word, sizeof(float)));
         HIP_CHECK(hipMemset(sync_word, 0, sizeof(float)));
