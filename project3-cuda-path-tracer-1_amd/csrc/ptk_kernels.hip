@@ -203,9 +203,12 @@ struct TraceLds {
     int* cnt;                    // [NT / 64]
 };
 // RAYS_IN_LDS: L.ray already holds the rays (written by other threads of the block, a barrier since); else every thread stores its own
-template <int NT, bool RAYS_IN_LDS, int LP = 16, bool WAVE = false>       // LP: primitives per pass of the pair list (list = NT * LP entries)
+// R3 (round 5, the eight-waves-per-SIMD experiment): the rays are SIX float planes ox, oy, oz, dx, dy, dz of NT entries at L.ray — 24 instead of 32 B per ray
+// (the fourth components carry nothing the search reads); RAYS_IN_LDS only.
+template <int NT, bool RAYS_IN_LDS, int LP = 16, bool WAVE = false, bool R3 = false>       // LP: primitives per pass of the pair list (list = NT * LP entries)
 __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const GeomStage& gs, const TraceLds& L, bool active, f3 ro, f3 rd, Analytic& a) {
     static_assert(!WAVE || NT == 64, "a wave-level group is one wave");
+    static_assert(!R3 || RAYS_IN_LDS, "the plane layout is written by the caller");
     constexpr int NW = NT / 64;
     constexpr int RB = NT == 512 ? 9 : 8;                 // bits of the ray index inside a list entry
     float4* s_ray = L.ray; float2* s_res = L.res; unsigned long long* s_best = L.best; unsigned short* s_list = L.list; int* s_cnt = L.cnt;
@@ -263,9 +266,15 @@ __device__ __forceinline__ void analytic_closest_lds(const SceneView& S, const G
                     const unsigned e = s_list[pi];
                     r = (int)(e & ((1u << RB) - 1u));
                     const int k = (int)(e >> RB);
-                    const float4 o4 = s_ray[r], d4 = s_ray[NT + r];
+                    f3 po, pd;
+                    if (R3) {
+                        const float* s_r3 = reinterpret_cast<const float*>(s_ray);
+                        po = mk3(s_r3[r], s_r3[NT + r], s_r3[2 * NT + r]); pd = mk3(s_r3[3 * NT + r], s_r3[4 * NT + r], s_r3[5 * NT + r]);
+                    } else {
+                        const float4 o4 = s_ray[r], d4 = s_ray[NT + r];
+                        po = mk3(o4.x, o4.y, o4.z); pd = mk3(d4.x, d4.y, d4.z);
+                    }
                     const GeomXfRef g = ref_xf(gs.xf, base + k, (c.diag >> k) & 1);
-                    const f3 po = mk3(o4.x, o4.y, o4.z), pd = mk3(d4.x, d4.y, d4.z);
 #ifdef PTK_DIAG_DOUBLE_TEST      // timing experiments only
                     { f3 po2 = po; asm volatile("" : "+v"(po2.x), "+v"(po2.y), "+v"(po2.z)); f3 P2 = mk3(0, 0, 0), N2 = mk3(0, 0, 0);
                       const float t2 = pi < Tc ? box_test(g, po2, pd, P2, N2) : sphere_test(g, po2, pd, P2, N2);
@@ -1609,6 +1618,9 @@ __device__ __forceinline__ int gather_source_w(const int* __restrict__ pref, con
 // geomID; the material id is a field of the primitive's staged record; triangleID is -1 without triangles): 80 B per path instead of 100.
 // The timed configuration is partly bound by HBM traffic (+32 B per path costs 5.7 %, measured): −24 % bytes per path-bounce.
 template <int MODE, bool GEN, bool SPLIT, bool COMPACT>
+#ifndef PTK_RAY3
+#define PTK_RAY3 0                  // 1: BSDF-mode k_shade_trace keeps its rays as six float planes in LDS (6 instead of 8 KB), see R3 there
+#endif
 #ifndef PTK_FUSED_WAVES_BSDF
 #define PTK_FUSED_WAVES_BSDF 7
 #endif
@@ -1633,10 +1645,15 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     // shared by the two phases: shading = materials + permutation / slot / source tables (3 x 1 KB); tracing = pair list
     __shared__ __attribute__((aligned(16))) unsigned char s_over[OVER];
     // the trace phase's LDS: rays (8 KB), the winners' hit points (6 KB), the ds_min keys (2 KB)
-    __shared__ float4 s_stage[4 * NT];
+    // R3 (-DPTK_RAY3=1, BSDF mode — no shadow phase borrows the upper half): the rays as six float planes, 6 KB; 20.1 instead of 22.1 KB per block, what
+    // an eighth block per CU needs (with PTK_FUSED_WAVES_BSDF=8: 64 VGPRs)
+    constexpr bool R3 = PTK_RAY3 && MODE == PTK_MODE_BSDF;
+    constexpr int RAY_U4 = R3 ? (3 * NT) / 2 : 2 * NT;        // float4 units the rays take
+    __shared__ float4 s_stage[RAY_U4 + 2 * NT];
     float4* s_ray = s_stage;
-    float2* s_res = reinterpret_cast<float2*>(s_stage + 2 * NT);
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_stage + 2 * NT + (3 * NT) / 2);
+    float* s_r3 = reinterpret_cast<float*>(s_stage);
+    float2* s_res = reinterpret_cast<float2*>(s_stage + RAY_U4);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_stage + RAY_U4 + (3 * NT) / 2);
     __shared__ int s_cnt[NW][NKEY];
     __shared__ int s_red[NW];
     __shared__ int s_tcnt[NW];
@@ -1683,7 +1700,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
     int total = 0;                         // survivors of the block
     // shadow ray of thread t -> slots 2t, 2t + 1 of the (still idle) upper half of the trace phase's LDS: s_res / s_best are first written
     // inside analytic_closest_lds
-    ShadowReq rq; rq.on = false; rq.slot = s_stage + 2 * NT + tid; rq.dstride = NT; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
+    ShadowReq rq; rq.on = false; rq.slot = s_stage + RAY_U4 + tid; rq.dstride = NT; rq.pix = 0; rq.contrib = mk3(0, 0, 0);
     int gen_pixw = 0;                      // GEN + COMPACT: the camera ray's pixel word, stored with the path state after the trace phase
     // ... when the scene is open (gen.late_stores: the host saw fewer than ~half of the camera rays of earlier iterations hit something);
     // otherwise before it, where the stores overlap the tracing (cornell.txt: 22.8 vs 22.6 Grays/s).  Same values either way.  (Deciding here
@@ -1718,8 +1735,13 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 st4(io.nxt.d_bnc, i, make_float4(d.x, d.y, d.z, __int_as_float(gen.trace_depth)));
                 st4(io.nxt.col_pdf, i, make_float4(1.f, 1.f, 1.f, -1.f));
             }
-            s_ray[tid] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
-            s_ray[NT + tid] = make_float4(d.x, d.y, d.z, 0.f);
+            if (R3) {
+                s_r3[tid] = gen.cam.pos.x; s_r3[NT + tid] = gen.cam.pos.y; s_r3[2 * NT + tid] = gen.cam.pos.z;
+                s_r3[3 * NT + tid] = d.x; s_r3[4 * NT + tid] = d.y; s_r3[5 * NT + tid] = d.z;
+            } else {
+                s_ray[tid] = make_float4(gen.cam.pos.x, gen.cam.pos.y, gen.cam.pos.z, 0.f);
+                s_ray[NT + tid] = make_float4(d.x, d.y, d.z, 0.f);
+            }
         }
     } else {
         // ---- shading phase: k_shade_binned's, with the compacted slot from the window tables
@@ -1847,8 +1869,13 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
                 st4(io.nxt.d_bnc, s2, make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces)));
                 st4(io.nxt.col_pdf, s2, make_float4(p.col.x, p.col.y, p.col.z, p.prevPdf));
             }
-            s_ray[my_rank] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix));          // hand the new ray to the thread that traces it
-            s_ray[NT + my_rank] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces));
+            if (R3) {
+                s_r3[my_rank] = p.o.x; s_r3[NT + my_rank] = p.o.y; s_r3[2 * NT + my_rank] = p.o.z;
+                s_r3[3 * NT + my_rank] = p.d.x; s_r3[4 * NT + my_rank] = p.d.y; s_r3[5 * NT + my_rank] = p.d.z;
+            } else {
+                s_ray[my_rank] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix));          // hand the new ray to the thread that traces it
+                s_ray[NT + my_rank] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(p.bounces));
+            }
         }
     }
     __syncthreads();                           // shading tables are dead, s_ray is complete: the pair list may overwrite s_over
@@ -1857,7 +1884,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         // ---- shadow phase (LightSampler::occulusionTest, lightSample.h:59-139) for the block's next-event samples.  Inside shade_path the
         // test is a per-lane candidate loop that runs max-over-lanes trips per wave and holds the shading state in registers meanwhile
         // (MIS: 109 VGPRs = four waves per SIMD; without it 87 = five).  Here: analytic primitives block-cooperatively, the BVH per lane.
-        const TraceLds Lsh = {s_stage + 2 * NT, nullptr, nullptr, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
+        const TraceLds Lsh = {s_stage + RAY_U4, nullptr, nullptr, reinterpret_cast<unsigned short*>(s_over), s_tcnt};
         bool occ = false;
         f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0); float s_minT = 0.f; int s_pix = 0;
         if (rq.on) { const float4 o4 = rq.slot[0], d4 = rq.slot[NT]; so = mk3(o4.x, o4.y, o4.z); s_minT = o4.w; sd = mk3(d4.x, d4.y, d4.z); s_pix = __float_as_int(d4.w); }
@@ -1877,7 +1904,8 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
         const bool active = tid < total;
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
         if (active) {
-            const float4 o4 = s_ray[tid], d4 = s_ray[NT + tid]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+            if (R3) { ro = mk3(s_r3[tid], s_r3[NT + tid], s_r3[2 * NT + tid]); rd = mk3(s_r3[3 * NT + tid], s_r3[4 * NT + tid], s_r3[5 * NT + tid]); }
+            else { const float4 o4 = s_ray[tid], d4 = s_ray[NT + tid]; ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z); }
         }
         Analytic a;
 #ifdef PTK_DIAG_PAD_VALU     // timing experiment only (tools/diag/issue_sensitivity.sh): N more vector instructions per wave — four independent fma chains on live
@@ -1891,7 +1919,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
             asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3));
         }
 #endif
-        if (gs.on) analytic_closest_lds<NT, true, LP>(S, gs, L, active, ro, rd, a);
+        if (gs.on) analytic_closest_lds<NT, true, LP, false, R3>(S, gs, L, active, ro, rd, a);
         else { a.t_min = FLT_MAX; a.geom = -1; a.P = mk3(0, 0, 0); a.NS = mk3(0, 0, 0); if (active) analytic_closest(S, gs, ro, rd, a); }
         if (!GEN) PTK_PHASE(0);                      // 4: (shadow phase +) closest hit: candidates, pair list, exact tests
         int flag = 0;
@@ -2006,7 +2034,7 @@ __global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ?
 // ------------------------------------------------------------------------------------------------------------------
 #define PTK_WW 64
 template <int MODE, bool GEN>
-__global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ? PTK_FUSED_WAVES_GEN : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : PTK_FUSED_WAVES_BSDF))))
+__global__ void __launch_bounds__(PTK_BLOCK, ((GEN && PTK_FUSED_WAVES_GEN > 0) ? PTK_FUSED_WAVES_GEN : (MODE == PTK_MODE_MIS ? PTK_FUSED_WAVES_MIS : (MODE == PTK_MODE_DIRECTLI ? PTK_FUSED_WAVES_DIRECT : (PTK_FUSED_WAVES_BSDF > 7 ? 7 : PTK_FUSED_WAVES_BSDF)))))      // (its LDS admits seven blocks per CU)
 k_shade_trace_w(SceneView S, GenArgs gen, int iter_arg, const int* __restrict__ iter_ptr, int depth, int n_arg, const int* __restrict__ d_n, TraceIO io, FilmArgs film,
                 int spp, int slot_bias, SegTail2 tail) {
     constexpr int NT = PTK_BLOCK, NW = NT / 64, WW = PTK_WW, NKEY = 6, MATS = 16, LP = 8;
