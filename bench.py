@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--in-flight", type=int, default=3, help="iterations in flight (ptk_set_iterations_in_flight)")
+    ap.add_argument("--in-flight", type=int, default=4, help="iterations in flight (ptk_set_iterations_in_flight)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay iterations from a hipGraph")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: per-GPU work fixed (weak) or whole-job work fixed (strong)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
@@ -360,7 +360,7 @@ def roofline_valu(scene_file, roof):
     rate = c["SQ_INSTS_VALU"] / (roof["avg_launch_us"] * 1e-6)
     return {"achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
             "insts_valu_per_launch": c["SQ_INSTS_VALU"], "kernel": roof.get("kernel"),
-            "note": "one kernel alone on one stream (its launch also ramps up and drains); with three iterations in flight the issue slots are still not what the pipeline "
+            "note": "one kernel alone on one stream (its launch also ramps up and drains); with several iterations in flight the issue slots are still not what the pipeline "
                     "is short of (valu_issue_timed.issue_sensitivity).  Peak = 1024 SIMDs x 2.4 GHz nominal / 4; packed instructions counted once; what an instruction really costs: profiles/r3_issue_cost.txt"}
 
 
@@ -629,7 +629,7 @@ def main():
         if N == 1 and not a.lean and os.path.exists(exe):
             # the drop-in C++ API (pathtraceInit / pathtrace / pathtraceFree of src/pathtrace.h:6-9, csrc/pathtrace.h) driven by the headless replay of
             # main.cpp's loop, own process: wall time of the pathtrace() calls + ONE pathtraceResolve() (the host image for saveImage), SURVEY 8(d)'s
-            # definition of the metric.  `value`: the API's defaults — three iterations in flight + graph replay with ordered accumulation (image
+            # definition of the metric.  `value`: the API's defaults — four iterations in flight + graph replay with ordered accumulation (image
             # bit-identical to one iteration at a time); `one_at_a_time`: --in-flight 1 --graph 0, the
             # reference's own schedule; `overlapped`: the knobs set explicitly; `eager`: a host image after EVERY call like pathtrace.cu:809-810
             import subprocess
@@ -642,7 +642,7 @@ def main():
             try:
                 cpp_api = dict(headless(), unit="Mrays/s",
                                config=("csrc/ptk_headless = the reference's loop, unedited: pathtraceInit + %d x pathtrace(nullptr, 0, it), the last call makes state.image current; API defaults (" % (a.steps * IPS))
-                                      + "3 iterations in flight + graph replay, ordered accumulation = the reference's running sum, bit-identical image)",
+                                      + "4 iterations in flight + graph replay, ordered accumulation = the reference's running sum, bit-identical image)",
                                one_at_a_time=headless("--in-flight", "1", "--graph", "0"),
                                overlapped=headless("--in-flight", str(a.in_flight), "--graph", str(a.graph)),
                                eager=headless("--in-flight", "1", "--graph", "0", "--eager"),
@@ -770,8 +770,8 @@ def main():
                                                        "+2-5 %%) or another wave slot (5 -> 6 -> 7 waves per SIMD: +8 %%, +6 %%), not fewer instructions or bytes.  profiles/%s_pmc_timed.json's figure is the "
                                                        "SERIALISED pace: rocprofv3 runs one dispatch at a time while it collects counters" % ROUND}
                     roofline["bound_timed"] = "latency"
-                    roofline["bound_note"] = ("TIMED configuration (three iterations in flight): neither HBM (frac_timed_measured) nor vector-ALU issue (valu_issue_timed.issue_sensitivity) is "
-                                              "saturated — wave slots x wave lifetime.  One launch ALONE on one stream (what frac prices): %s" % roofline["bound_note"])
+                    roofline["bound_note"] = ("TIMED configuration (%d iterations in flight): neither HBM (frac_timed_measured) nor vector-ALU issue (valu_issue_timed.issue_sensitivity) is "
+                                              "saturated — wave slots x wave lifetime.  One launch ALONE on one stream (what frac prices): %s" % (a.in_flight, roofline["bound_note"]))
                 except Exception as e:
                     out["valu_issue_timed"] = {"error": str(e)[:200]}
                 per_iter = 0.0

@@ -15,7 +15,7 @@
 // Timing (bench.py `cpp_api`): --warmup W renders W untimed iterations first (then waits for the GPU); the timed region is the remaining
 // pathtrace() calls including the resolve the last one makes — what a viewer that saves the image at the end pays.  --eager = PTK_EAGER_IMAGE=1
 // (the image copied after every call, pathtrace.cu:809-810), --in-flight / --tiles / --graph are the ptk_set_* knobs; without them pathtraceInit
-// chooses three iterations in flight + graph replay with ordered accumulation in every sample mode (image bit-identical to one at a time).
+// chooses four iterations in flight + graph replay with ordered accumulation in every sample mode (image bit-identical to one at a time).
 // --reinit-at N: pathtraceFree() + pathtraceInit() again after iteration N and start over (what the viewer does on a camera / mode change).
 //
 // RCCL (round 5; north star: "independent pixel tiles shard across the GPUs of one node with an RCCL reduce of the accumulated radiance buffer over

@@ -29,6 +29,11 @@ __attribute__((weak)) SampleMode sampleMode = MIS;       // main.cpp:20 (the app
 namespace {
 
 constexpr int kMaxLanes = 16;
+// Iterations in flight the C++ API starts with (pathtraceInit) = one lane per hardware queue of the lanes' pool (lane_stream_create).  Measured against
+// three, Grays/s (profiles/r5_ab_lane_queues.txt): cornell 400^2 depth 4 12.9 -> 15.6 (MIS 12.1 -> 13.8), textureEnv 15.9 -> 18.3, obj_test 13.9 -> 15.2,
+// mis_test 1024^2 depth 16 MIS 18.3 -> 19.2 / BSDF 24.5 -> 27.7, bunny 6.14 -> 6.56 (MIS 5.62 -> 6.01), metallic 14.7 -> 15.2, cornell 800^2 +-1 %; five or
+// more share queues again and lose.
+constexpr int kDefaultLanes = 4;
 
 struct Lane {
     hipStream_t stream = nullptr;
@@ -209,9 +214,27 @@ bool inline_bvh_choice(int which) {
     return which == 0 && g.scene && g.scene->tempDevScene.tri_num > 0 && g.scene->tempDevScene.tri_num <= max_tris;
 }
 
+// The lanes' streams and the hardware queues behind them.  The HIP runtime maps a process's streams onto at most GPU_MAX_HW_QUEUES (4) hardware
+// queues PER PRIORITY LEVEL, and streams that share a queue serialise behind each other's event waits (profiles/r4_tiles_hw_queues.txt).  The null
+// stream and the host's own streams live in the normal-priority pool, so a fourth lane there lands on a queue another stream already uses.
+// Round 5: the lanes are created in the HIGH-priority pool, whose four queues then belong to the lanes alone — what GPU_MAX_HW_QUEUES=8 bought, without
+// an environment variable the host would have to set before its first HIP call.  Four lanes: 4.96 -> 6.56 Grays/s on the bunny scene (three: 6.14),
+// mis_test 1024^2 14.4 -> 19.2 (three: 18.3), cornell 400^2 depth 4 12.9 -> 15.6; with three lanes nothing changes (profiles/r5_ab_lane_queues.txt).
+// PTK_LANE_PRIORITY (A/B knob): 1 (default) = as above; 0 = every lane at normal priority (rounds 2-4); 2 = lanes alternate between the two pools (up
+// to eight queues; measured worse: the pools are served with different priority).
+hipError_t lane_stream_create(hipStream_t* s, int idx) {
+    static const int policy = getenv("PTK_LANE_PRIORITY") ? atoi(getenv("PTK_LANE_PRIORITY")) : 1;
+    if (policy == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    const int prio = (policy == 1 || (idx & 1) == 0) ? greatest : 0;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+}
+
 int lane_init(Lane& l, int idx) {
     int rc;
-    hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    hipError_t e = lane_stream_create(&l.stream, idx);
     if (e != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     if ((e = hipEventCreateWithFlags(&l.counts_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
@@ -1030,7 +1053,7 @@ int ptk_timer_stop(float* ms) {
 // ---------------------------------------------------------------- C++ API (pathtrace.h)
 void InitDataContainer(GuiDataContainer* guiData) { g.gui = guiData; }
 
-// Schedule of the C++ API, chosen at pathtraceInit (the four reference signatures have no room for knobs).  DEFAULT: three iterations in flight +
+// Schedule of the C++ API, chosen at pathtraceInit (the four reference signatures have no room for knobs).  DEFAULT: kDefaultLanes (four) iterations in flight +
 // hipGraph replay with ordered accumulation — scene->state.image is bit-identical to one iteration at a time, i.e. to the reference's running sum,
 // in every sample mode (flush_merges; MIS gets one plane per bounce, which is decided by the mode at pathtraceInit: the viewer re-initialises on a
 // sample-mode change, main.cpp:173-201, preview.cpp:247).  Overrides: PTK_IN_FLIGHT=<L> (1 = the reference's own schedule), PTK_TILES=<K>,
@@ -1040,7 +1063,7 @@ void pathtraceInit(Scene* scene) {
     if (!g.live) {
         const bool env_sched = getenv("PTK_IN_FLIGHT") || getenv("PTK_TILES") || getenv("PTK_GRAPH");
         if (!g.sched_explicit && !env_sched) {
-            g.want_lanes = 3; g.use_graph = true; g.want_tiles = 1;
+            g.want_lanes = kDefaultLanes; g.use_graph = true; g.want_tiles = 1;
         }
         if (const char* e = getenv("PTK_IN_FLIGHT")) { const int l = atoi(e); if (l >= 1 && l <= kMaxLanes) g.want_lanes = l; }
         if (const char* e = getenv("PTK_GRAPH")) g.use_graph = atoi(e) != 0;

@@ -925,13 +925,13 @@ def test_iterations_in_flight_keep_the_reference_order(ptk, orc, torch_cuda, nam
     o.close()
     assert seq.sum() > 0
     imgs = {}
-    for lanes in (1, 3):
+    for lanes in (1, 3, 4):           # (four = the C++ API's and bench.py's default since round 5: one lane per hardware queue of the lanes' pool)
         r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
         for it in range(1, 12):
             r.iterate(it)
         imgs[lanes] = r.image(); r.close()
-    assert np.array_equal(imgs[1], seq), int((imgs[1] != seq).any(axis=1).sum())
-    assert np.array_equal(imgs[3], seq), int((imgs[3] != seq).any(axis=1).sum())
+    for lanes in (1, 3, 4):
+        assert np.array_equal(imgs[lanes], seq), (lanes, int((imgs[lanes] != seq).any(axis=1).sum()))
 
 
 @pytest.mark.parametrize("name,res,depth,mode,iters", [("cornell.txt", (400, 400), 8, "MIS", 240), ("cornell.txt", None, -1, "BSDF", 96), ("mis_test.txt", (512, 512), 16, "MIS", 240),
@@ -942,14 +942,15 @@ def test_long_render_in_flight_is_the_one_at_a_time_render(ptk, torch_cuda, name
     m = MODES[mode]
     s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
     imgs = []
-    for lanes in (1, 3, 3):
+    for lanes in (1, 3, 4, 4):
         r = ptk.Renderer(s, m, in_flight=lanes, graph=lanes > 1)
         for it in range(1, iters + 1):
             r.iterate(it)
         imgs.append(r.image()); rays = r.ray_total(); r.close()
     assert imgs[0].sum() > 0
     assert np.array_equal(imgs[1], imgs[0]), int((imgs[1] != imgs[0]).any(axis=1).sum())
-    assert np.array_equal(imgs[2], imgs[1])
+    assert np.array_equal(imgs[2], imgs[0]), int((imgs[2] != imgs[0]).any(axis=1).sum())
+    assert np.array_equal(imgs[3], imgs[2])
 
 
 @pytest.mark.parametrize("mode,ordered", [("MIS", 1), ("BSDF", 0), ("MIS", 0), ("DIRECT", -1)])
@@ -1169,17 +1170,17 @@ def test_reference_scene_without_camera_is_refused(ptk, torch_cuda):
 
 
 def test_benchmarked_configuration_full_size(ptk, orc, torch_cuda):
-    """What bench.py times by default: cornell.txt 800x800 depth 8, BSDF, THREE iterations in flight + hipGraph
-    replay, six iterations (every lane replays its graph): per-iteration live counts == oracle, image == the oracle's PLAIN SEQUENTIAL
+    """What bench.py times by default: cornell.txt 800x800 depth 8, BSDF, FOUR iterations in flight + hipGraph
+    replay, nine iterations (every lane replays its graph): per-iteration live counts == oracle, image == the oracle's PLAIN SEQUENTIAL
     render — the reference's own running sum (ordered accumulation: BSDF adds once per pixel and iteration) — bit for bit."""
-    name, lanes = "cornell.txt", 3
+    name, lanes = "cornell.txt", 4
     s = ptk.Scene(os.path.join(SC, name)); o = orc.Scene(os.path.join(SC, name))
     assert (s.width, s.height, s.trace_depth) == (800, 800, 8)
     r = ptk.Renderer(s, ptk.MODE_BSDF, in_flight=lanes, graph=True)
     ref = np.zeros((o.P, 3), np.float32)
     orc.set_threads(host_threads())
     try:
-        for it in range(1, 7):
+        for it in range(1, 10):
             r.iterate(it)
             _, live = o.pathtrace(ptk.MODE_BSDF, it, ref)
             counts, _ = r.live_counts()
