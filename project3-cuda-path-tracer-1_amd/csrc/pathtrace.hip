@@ -228,7 +228,9 @@ hipError_t lane_stream_create(hipStream_t* s, int idx) {
     int least = 0, greatest = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e != hipSuccess) return e;
-    const int prio = (policy == 1 || (idx & 1) == 0) ? greatest : 0;
+    int prio = greatest;
+    if (policy == 2) prio = (idx & 1) == 0 ? greatest : 0;
+    if (policy == 3) prio = idx % 3 == 0 ? greatest : (idx % 3 == 1 ? 0 : least);      // three pools: up to twelve queues
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
 }
 
