@@ -89,6 +89,11 @@ struct RenderContext {
     // batched merges (round 5): the iterations of up to `merge_batch` consecutive calls — consecutive lanes, the same plane set — are folded into
     // the image by ONE k_merge_planes launch, in call order; a lane alternates between n_sets = 2 sets of planes so that it never waits for a merge
     int merge_batch = 1, n_sets = 1;
+    // merge stream (round 5, PTK_MERGE_STREAM): the merges of ALL lanes run on one stream of their own, in call order (= the order of that stream), in
+    // the normal-priority pool where its hardware queue is shared with no lane (lane_stream_create); lanes alternate between two plane sets
+    hipStream_t merge_stream = nullptr;
+    hipEvent_t merge_done = nullptr;    // recorded behind the latest merge on merge_stream (join_on_lane0)
+    bool merge_wait_resolved = false;   // the next merge must wait for lane 0's asynchronous reader of the image (image_reader_enqueued)
     int pend_first = 0, pend_n = 0, pend_set = 0;      // lanes pend_first .. pend_first + pend_n - 1 hold unmerged iterations in set pend_set
     unsigned long long* ray_total = nullptr;
     int P = 0, capacity = 0, traceDepth = 0;
@@ -127,7 +132,7 @@ int alloc_paths(PtkPaths& b, int cap) {
 }
 void free_paths(PtkPaths& b) { dfree(b.o_pix); dfree(b.d_bnc); dfree(b.col_pdf); }
 
-void sync_all() { for (Lane& l : g.lanes) if (l.stream) (void)hipStreamSynchronize(l.stream); }
+void sync_all() { for (Lane& l : g.lanes) if (l.stream) (void)hipStreamSynchronize(l.stream); if (g.merge_stream) (void)hipStreamSynchronize(g.merge_stream); }
 
 int context_free() {
     sync_all();
@@ -150,6 +155,9 @@ int context_free() {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     g.lanes.clear();
+    if (g.merge_stream) { (void)hipStreamDestroy(g.merge_stream); g.merge_stream = nullptr; }
+    if (g.merge_done) { (void)hipEventDestroy(g.merge_done); g.merge_done = nullptr; }
+    g.merge_wait_resolved = false;
     if (g.host_image_reg) { (void)hipHostUnregister(g.host_image_reg); g.host_image_reg = nullptr; }
     if (g.image != g.planes) dfree(g.image);
     g.image = nullptr;
@@ -378,6 +386,12 @@ int context_init(Scene* scene) {
         const char* mb = getenv("PTK_MERGE_BATCH");
         g.merge_batch = mb ? std::max(1, std::min(atoi(mb), g.n_lanes)) : 1;
         if (g.merge_batch > 1) g.n_sets = 2;
+        const char* ms = getenv("PTK_MERGE_STREAM");
+        if (g.merge_batch == 1 && ms && atoi(ms) != 0) {
+            g.n_sets = 2;
+            if ((e = hipStreamCreateWithFlags(&g.merge_stream, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+            if ((e = hipEventCreateWithFlags(&g.merge_done, hipEventDisableTiming)) != hipSuccess) return (int)e;
+        }
     }
     g.pend_n = 0;
     const size_t n_planes = n_basic * g.n_depth * g.n_sets;
@@ -634,6 +648,19 @@ static void reset_hints() { for (Lane& l : g.lanes) { l.full_bounces = g.traceDe
 static int flush_merges() {
     if (!g.ordered || g.pend_n == 0) return 0;
     hipError_t e;
+    if (g.merge_stream) {
+        // one iteration per merge, every merge on the merge stream: its order IS the call order; the lane goes on with its other plane set at once
+        Lane& L = g.lanes[g.pend_first];
+        if ((e = hipEventRecord(L.done, L.stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamWaitEvent(g.merge_stream, L.done, 0)) != hipSuccess) return (int)e;
+        if (g.merge_wait_resolved) { if ((e = hipStreamWaitEvent(g.merge_stream, g.resolved, 0)) != hipSuccess) return (int)e; g.merge_wait_resolved = false; }
+        const int rc = launch_merge_planes(g.image, L.plane_sets[g.pend_set], L.flag_sets[g.pend_set], g.spp * g.n_depth, g.P, g.merge_stream);
+        if (rc) return rc;
+        if ((e = hipEventRecord(L.set_free[g.pend_set], g.merge_stream)) != hipSuccess) return (int)e;
+        L.set_busy[g.pend_set] = true;
+        g.pend_n = 0;
+        return 0;
+    }
     Lane& M = g.lanes[g.pend_first + g.pend_n - 1];          // the merge runs behind the last iteration it folds, on that lane's stream
     for (int k = 0; k < g.pend_n - 1; ++k) {
         Lane& o = g.lanes[g.pend_first + k];
@@ -731,6 +758,11 @@ int render_iteration(unsigned char* pbo, int step) {
 
 // all lanes' work so far -> visible to lane 0's stream (event edges only, no host wait)
 int join_on_lane0() {
+    if (g.merge_stream) {
+        hipError_t e = hipEventRecord(g.merge_done, g.merge_stream);
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipStreamWaitEvent(g.lanes[0].stream, g.merge_done, 0)) != hipSuccess) return (int)e;
+    }
     for (size_t i = 1; i < g.lanes.size(); ++i) {
         hipError_t e = hipEventRecord(g.lanes[i].done, g.lanes[i].stream);
         if (e != hipSuccess) return (int)e;
@@ -757,6 +789,7 @@ int image_reader_enqueued() {
     const hipError_t e = hipEventRecord(g.resolved, g.lanes[0].stream);
     if (e != hipSuccess) return (int)e;
     for (size_t i = 1; i < g.lanes.size(); ++i) g.lanes[i].wait_resolved = true;
+    if (g.merge_stream) g.merge_wait_resolved = true;
     return 0;
 }
 

@@ -2958,11 +2958,12 @@ namespace ptk {
 // Pooled wide walk or not (k_traverse_pool).  Measured on the bunny scene, Grays/s, three iterations in flight, k_traverse_wide / pool 256 / 512 /
 // 1 024 (profiles/r5_ab_pooled_walk.txt): 800 x 800 depth 8 (142 k listed rays per launch): 6.12 / 6.01 / 5.62 / 4.39 — too few rays to keep the
 // machine in waves once four share a group; one iteration at a time 3.48 / 2.67 / 2.02 / 1.28; 2 048 x 2 048 depth 16 (0.9 M listed rays): 6.67 /
-// 6.91 / 7.08 / 6.53.  Hence: pools of 512 from two million paths per launch on, and only with iterations in flight.  PTK_WIDE_POOL=<n> forces a
-// chunk (0 = off) for A/B runs and the parity tests.
+// 6.91 / 7.08 / 6.53.  With FOUR iterations in flight (the default since the end of round 5; gpurun_out s2_f, profiles/r5_ab_lane_queues.txt section 6), wide /
+// 256 / 512: 800^2 6.56 / 6.59 / 6.44; 1 280^2 depth 8 6.84 / 7.00 / 7.20; 2 048^2 depth 16 6.79 / 7.04 / 7.24.  Hence: pools of 512 from 1.5 million
+// paths per launch on, and only with iterations in flight.  PTK_WIDE_POOL=<n> forces a chunk (0 = off) for A/B runs and the parity tests.
 int pick_wide_pool(int capacity, int n_lanes) {
     if (const char* e = getenv("PTK_WIDE_POOL")) { const int v = atoi(e); return v < 0 ? 0 : (v > 2048 ? 2048 : v); }
-    return (n_lanes > 1 && capacity >= (1 << 21)) ? 512 : 0;
+    return (n_lanes > 1 && capacity >= (3 << 19)) ? 512 : 0;
 }
 int local_path_count(int W, int H, int n_parts, int part, int tile_rows) {
     if (n_parts <= 1) return W * H;

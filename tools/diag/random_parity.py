@@ -61,7 +61,7 @@ def one_case(seed, tmp):
     rng = np.random.default_rng(seed)
     txt, info = scene_text(rng)
     path = os.path.join(tmp, f"rnd{seed}.txt"); open(path, "w").write(txt)
-    mode = int(rng.integers(0, 3)); lanes = int(rng.integers(1, 4)); graph = bool(rng.integers(0, 2)) or lanes > 1
+    mode = int(rng.integers(0, 3)); lanes = int(rng.integers(1, 5)); graph = bool(rng.integers(0, 2)) or lanes > 1
     part = (1, 0, 1); spp = 1
     if rng.uniform() < 0.3:
         n = int(rng.integers(2, 5)); part = (n, int(rng.integers(0, n)), int(rng.choice([1, 4, 8]))); spp = int(rng.integers(1, 4))
