@@ -865,12 +865,20 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_wide(SceneView S, c
 // LDS: rays 32 B x chunk + stacks 12.8 KB + staged top nodes 2.3 KB (chunk 512: 31 KB, five blocks per CU).
 // ------------------------------------------------------------------------------------------------------------------
 #define PTK_POOL_IDLE_LANES 16    // a wave refills when at least this many of its 64 lanes are idle
-template <int LPR>
-__global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_pool(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
+// S16 (second session of round 5): the per-ray stacks hold 16-bit child references (15 bits of index + the leaf flag) when the tree has fewer than 32 768 nodes
+// and leaves — 6.4 instead of 12.8 KB of LDS per block with pairs, so that a pool of 256 rays fits eight blocks per CU (16.9 KB) like k_traverse_wide does, and
+// the kernel is compiled for eight waves per SIMD.  Same references, same order: bit-identical.
+__device__ __forceinline__ unsigned short pool_pack16(unsigned w) { return (unsigned short)((w & 0x7fffu) | ((w >> 16) & 0x8000u)); }
+__device__ __forceinline__ unsigned pool_unpack16(unsigned h) { return (h & 0x7fffu) | ((h & 0x8000u) << 16); }
+template <bool S16> struct PoolStack { typedef unsigned T; };
+template <> struct PoolStack<true> { typedef unsigned short T; };
+template <int LPR, bool S16>
+__global__ void __launch_bounds__(PTK_WIDE_BLOCK, S16 ? 8 : 1) k_traverse_pool(SceneView S, const unsigned* __restrict__ list_count, const int* __restrict__ list,
                                                               PtkPaths paths, PtkHits hits, int* __restrict__ valid, const int* __restrict__ srcidx, int chunk) {
     constexpr int GROUPS = PTK_WIDE_BLOCK / LPR, NCH = 8 / LPR;
+    typedef typename PoolStack<S16>::T StackT;
     __shared__ uint4 s_top[(PTK_WIDE_TOP > 0 ? PTK_WIDE_TOP : 1) * 9];
-    __shared__ unsigned s_stack[GROUPS * PTK_WIDE_STRIDE];
+    __shared__ StackT s_stack[GROUPS * PTK_WIDE_STRIDE];
     __shared__ int s_next;
     extern __shared__ float4 s_rays[];                           // [chunk][2]: (origin, t0), (direction, ray index)
     const int m = (int)*list_count;
@@ -890,7 +898,7 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_pool(SceneView S, c
     __syncthreads();
     const int q = threadIdx.x & (LPR - 1);
     const int leader = (threadIdx.x & 63) & ~(LPR - 1);            // first lane of the group within the wave
-    unsigned* stk = s_stack + (threadIdx.x / LPR) * PTK_WIDE_STRIDE;
+    StackT* stk = s_stack + (threadIdx.x / LPR) * PTK_WIDE_STRIDE;
     WideRay r; WideFrame f;
     r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0); r.inv = mk3(0, 0, 0); r.t_min = 0.f; r.tri = -1; r.u = 0.f; r.v = 0.f; r.dir = 0; f.selN = f.selF = 0u;
     int ray = -1, sp = 0;
@@ -964,7 +972,7 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_pool(SceneView S, c
                 if (!overflow) {
 #pragma unroll
                     for (int k = 0; k < NCH; ++k)
-                        if (hit[k]) stk[sp + nh - 1 - __popc(H & wide_before(ch[k], r.dir))] = ch[k].w;
+                        if (hit[k]) stk[sp + nh - 1 - __popc(H & wide_before(ch[k], r.dir))] = S16 ? (StackT)pool_pack16(ch[k].w) : (StackT)ch[k].w;
                     sp += nh;
                     finished = sp == 0;
                 }
@@ -981,7 +989,7 @@ __global__ void __launch_bounds__(PTK_WIDE_BLOCK) k_traverse_pool(SceneView S, c
                     valid[ray] = PTK_VALID_TRI;
                 }
                 active = false;
-            } else { --sp; cur = stk[sp]; }
+            } else { --sp; cur = S16 ? pool_unpack16(stk[sp]) : (unsigned)stk[sp]; }
         }
     }
 }
@@ -2862,8 +2870,12 @@ static void launch_wide_walk(const SceneView& S, int g, int lpr, int pool, const
     if (pool > 0 && S.wide_width == 8) {             // (the pooled walk exists for 8-wide nodes only)
         const int blocks = (g * PTK_BLOCK + pool - 1) / pool;
         const size_t lds = (size_t)pool * 2 * sizeof(float4);
-        if (lpr == 2) k_traverse_pool<2><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
-        else k_traverse_pool<4><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
+        static const int s16_forced = getenv("PTK_POOL_S16") ? atoi(getenv("PTK_POOL_S16")) : -1;      // (A/B knob: 0 = 32-bit stacks)
+        const bool s16 = S.n_wnodes < 32768 && S.n_tris < 32768 && s16_forced != 0;
+        if (lpr == 2) { if (s16) k_traverse_pool<2, true><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
+                        else k_traverse_pool<2, false><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool); }
+        else { if (s16) k_traverse_pool<4, true><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
+               else k_traverse_pool<4, false><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool); }
         return;
     }
     if (S.wide_width == 16) {

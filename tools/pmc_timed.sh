@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/pmc_timed.sh <round>   -> gpurun_out/pmc_timed_<round>/ and profiles/<round>_pmc_timed.json
-# counters of the TIMED configuration (3 iterations in flight, graph replay), one rocprofv3 --pmc pass with --kernel-trace only; the
+# counters of the TIMED configuration (the default: four iterations in flight, graph replay), one rocprofv3 --pmc pass with --kernel-trace only; the
 # program itself after `--`, no hop.  Summed over every dispatch of the run by tools/pmc_timed_sum.py.
 set -o pipefail
 rd=${1:-r4}

@@ -24,7 +24,7 @@ out = {"frac": round(valu / (simds * gui), 4) if gui else None, "valu_active_cyc
        "effective_clock_GHz": round(gui / dur_ns, 3) if dur_ns else None, "dispatches": len(disp), "kernel_time_ms": round(dur_ns / 1e6, 3),
        "SQ_INSTS_VALU": round(tot.get("SQ_INSTS_VALU", 0)), "SQ_WAVES": round(tot.get("SQ_WAVES", 0)), "SQ_BUSY_CYCLES": round(tot.get("SQ_BUSY_CYCLES", 0)),
        "bench_value_under_pmc": bench.get("value"), "bench_config": bench.get("config", {}).get("workload"),
-       "note": "all dispatches of `bench.py --lean 1` (3 iterations in flight, graph replay) under rocprofv3 --pmc; dispatches are serialised while counters are collected, "
+       "note": "all dispatches of `bench.py --lean 1` (the default: four iterations in flight, graph replay) under rocprofv3 --pmc; dispatches are serialised while counters are collected, "
                "so this is the vector-ALU share of the kernels' own GPU-active cycles (GRBM_GUI_ACTIVE / 8 XCDs), not of the overlapped wall time",
        "source": "tools/pmc_timed.sh"}
 print(json.dumps(out, indent=1))

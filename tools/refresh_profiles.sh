@@ -42,8 +42,8 @@ python3 tools/collect_profiles.py $RD > /dev/null
 fi
 if [ "$PART" = 1 ]; then find $out -name "*.csv" -size +2M -delete; find $out -name "*.db" -delete; exit 0; fi
 bash tools/pmc_wait.sh $RD > $out/pmc_wait.log 2>&1 || { tail -5 $out/pmc_wait.log; exit 1; }      # where the wait goes (round 5) -> profiles/<round>_pmc_wait.json
-# timelines of the steady state, three iterations in flight (tools/timeline.py): how many kernels run at once, per-queue gaps
-for c in "cornell.txt 0 3 600" "bunny_cornell.txt 0 3 400"; do set -- $c; tag=${1%%.txt}
+# timelines of the steady state, four iterations in flight (tools/timeline.py): how many kernels run at once, per-queue gaps
+for c in "cornell.txt 0 4 800" "bunny_cornell.txt 0 4 400"; do set -- $c; tag=${1%%.txt}
   rocprofv3 --kernel-trace --output-format csv -d $out/tl_$tag -o t -- python3 tools/diag/render_loop.py $c > $out/tl_$tag.txt 2> $out/tl_$tag.err || true
   f=$(find $out/tl_$tag -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { echo "== $c: $(cat $out/tl_$tag.txt) (under rocprofv3 --kernel-trace)"; python3 tools/timeline.py $f; } > profiles/${RD}_timeline_$tag.txt 2>&1
   rm -rf $out/tl_$tag; cp profiles/${RD}_timeline_$tag.txt $out/
