@@ -18,6 +18,7 @@
 #ifdef PTK_TEST_HOOKS
 #include "../../include/ptk_test_hooks.h"
 #endif
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -29,6 +30,10 @@ __attribute__((weak)) SampleMode sampleMode = MIS;       // main.cpp:20 (the app
 namespace {
 
 constexpr int kMaxLanes = 16;
+// PTK_HOST_TIMING=1 (diagnostic): host time spent inside hipGraphLaunch, in the merge's three runtime calls and in the rest of ptk_pathtrace, printed when the context is freed
+struct HostTiming { bool on = false; double graph_us = 0, merge_us = 0, call_us = 0, graph_max = 0; long calls = 0; } g_ht;
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Iterations in flight the C++ API starts with (pathtraceInit) = one lane per hardware queue of the lanes' pool (lane_stream_create).  Measured against
 // three, Grays/s (profiles/r5_ab_lane_queues.txt): cornell 400^2 depth 4 12.9 -> 15.6 (MIS 12.1 -> 13.8), textureEnv 15.9 -> 18.3, obj_test 13.9 -> 15.2,
 // mis_test 1024^2 depth 16 MIS 18.3 -> 19.2 / BSDF 24.5 -> 27.7, bunny 6.14 -> 6.56 (MIS 5.62 -> 6.01), metallic 14.7 -> 15.2, cornell 800^2 +-1 %; five or
@@ -136,6 +141,10 @@ void sync_all() { for (Lane& l : g.lanes) if (l.stream) (void)hipStreamSynchroni
 
 int context_free() {
     sync_all();
+    if (g_ht.on && g_ht.calls > 0)
+        std::fprintf(stderr, "ptk host timing: %ld calls, %.1f us per call on the host: hipGraphLaunch %.1f (max %.0f), merge enqueue %.1f, rest %.1f\n", g_ht.calls, g_ht.call_us / g_ht.calls,
+                     g_ht.graph_us / g_ht.calls, g_ht.graph_max, g_ht.merge_us / g_ht.calls, (g_ht.call_us - g_ht.graph_us - g_ht.merge_us) / g_ht.calls);
+    g_ht = HostTiming(); g_ht.on = getenv("PTK_HOST_TIMING") && atoi(getenv("PTK_HOST_TIMING")) != 0;
     g_debug_slot_shift = g_debug_slot_shift_deep = 0;      // a test that died between set and reset must not shift the keys of later renders
     for (Lane& l : g.lanes) {
         free_paths(l.bufA); free_paths(l.bufB);
@@ -622,7 +631,9 @@ int replay_iteration(Lane& L, int iter, int mode) {
         if ((e = hipMemcpyAsync(L.iter_dev, &iter, sizeof(int), hipMemcpyHostToDevice, L.stream)) != hipSuccess) return (int)e;
         if ((e = hipStreamSynchronize(L.stream)) != hipSuccess) return (int)e;     // &iter is a stack address
     }
+    const double t0 = g_ht.on ? now_us() : 0.0;
     if ((e = hipGraphLaunch(Q.exec, L.stream)) != hipSuccess) return (int)e;
+    if (g_ht.on) { const double d = now_us() - t0; g_ht.graph_us += d; if (d > g_ht.graph_max) g_ht.graph_max = d; }
     L.expected_iter = iter + (g.tiles ? 1 : g.n_lanes) * g.n_shards;
     return 0;
 }
@@ -714,7 +725,11 @@ static int lane_iteration(Lane& L, int iter, int mode) {
     if (g.use_graph && !g_prof.on && !L.ws.stats) rc = replay_iteration(L, iter, mode);
     else { L.expected_iter = -1; rc = enqueue_iteration(L, iter, mode, false); }
     if (rc || (rc = request_counts(L))) return rc;
-    return g.tiles ? 0 : note_unmerged((int)(&L - &g.lanes[0]));
+    if (g.tiles) return 0;
+    const double t0 = g_ht.on ? now_us() : 0.0;
+    rc = note_unmerged((int)(&L - &g.lanes[0]));
+    if (g_ht.on) g_ht.merge_us += now_us() - t0;
+    return rc;
 }
 
 int render_iteration(unsigned char* pbo, int step) {
@@ -823,7 +838,9 @@ int ptk_pathtrace_free(void) { return context_free(); }
 
 int ptk_pathtrace(unsigned char* pbo, int frame, int iter) {
     (void)frame;
+    const double t0 = g_ht.on ? now_us() : 0.0;
     int rc = render_iteration(pbo, iter);
+    if (g_ht.on) { g_ht.call_us += now_us() - t0; ++g_ht.calls; }
     if (rc || !pbo) return rc;
     if ((rc = resolve_image())) return rc;
     const Camera& cam = g.scene->state.camera;

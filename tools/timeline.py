@@ -48,6 +48,16 @@ for q, v in sorted(byq.items()):
     b = sum(e - s for s, e, _ in v) / 1e3
     print(f"queue {q}: {len(v)} dispatches, busy {b:.0f} us ({b / wall:.3f}), gaps mean {gaps.mean():.2f} median {np.median(gaps):.2f} p90 {np.percentile(gaps, 90):.2f} us, "
           f"total {gaps[gaps > 0].sum():.0f} us ({gaps[gaps > 0].sum() / wall:.3f})")
+# which dispatch the queue was idle BEFORE (round 5, second session): gap to the previous dispatch on the same queue, by kernel
+def short(n): return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
+gk = defaultdict(list)
+for q, v in byq.items():
+    for i in range(1, len(v)): gk[short(v[i][2])].append(max(0.0, (v[i][0] - v[i - 1][1]) / 1e3))
+print("idle time of a queue before a dispatch, by kernel (us): calls, mean, median, p90, share of all idle time")
+tot_gap = sum(sum(v) for v in gk.values())
+for n, v in sorted(gk.items(), key=lambda kv: -sum(kv[1])):
+    a = np.array(v)
+    print(f"  {n:60s} {len(v):6d} {a.mean():8.2f} {np.median(a):8.2f} {np.percentile(a, 90):8.2f}   {a.sum() / max(tot_gap, 1e-9):.3f}")
 byk = defaultdict(list)
 for s, e, _, n in rows: byk[n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]].append((e - s) / 1e3)
 for n, v in sorted(byk.items(), key=lambda kv: -sum(kv[1])):
