@@ -2870,7 +2870,8 @@ static void launch_wide_walk(const SceneView& S, int g, int lpr, int pool, const
     if (pool > 0 && S.wide_width == 8) {             // (the pooled walk exists for 8-wide nodes only)
         const int blocks = (g * PTK_BLOCK + pool - 1) / pool;
         const size_t lds = (size_t)pool * 2 * sizeof(float4);
-        static const int s16_forced = getenv("PTK_POOL_S16") ? atoi(getenv("PTK_POOL_S16")) : -1;      // (A/B knob: 0 = 32-bit stacks)
+        const char* s16_env = getenv("PTK_POOL_S16");                                                  // (A/B and test knob: 0 = 32-bit stacks; read per launch, a test flips it)
+        const int s16_forced = s16_env ? atoi(s16_env) : -1;
         const bool s16 = S.n_wnodes < 32768 && S.n_tris < 32768 && s16_forced != 0;
         if (lpr == 2) { if (s16) k_traverse_pool<2, true><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool);
                         else k_traverse_pool<2, false><<<blocks, PTK_WIDE_BLOCK, lds, st>>>(S, queue, list, paths, hits, valid, srcidx, pool); }

@@ -362,25 +362,25 @@ def test_wide_walk_equals_threaded_walk_full_size(ptk, torch_cuda, name, mode):
 def test_pooled_walk_equals_one_ray_per_group(ptk, orc, torch_cuda, monkeypatch, mode, pipeline):
     """Round 5: k_traverse_pool (a block's groups draw work-list rays from a pool staged in LDS and refill when a quarter of a wave is idle) walks
     every ray exactly like k_traverse_wide does — only which lanes walk which ray changes.  Radiance and live counts with pools of 64 (every block
-    starts half empty), 512 and 2 048 rays == one ray per group == the oracle, one and three iterations in flight; the automatic choice (pools from
-    two million paths per launch on, with iterations in flight) is checked on the 2048 x 2048 frame of BASELINE configs[4] against pools switched off."""
+    starts half empty), 512 and 2 048 rays, with 16- and 32-bit per-ray stacks, == one ray per group == the oracle, one and four iterations in flight; the automatic choice (pools from
+    1.5 million paths per launch on, with iterations in flight) is checked on the 2048 x 2048 frame of BASELINE configs[4] against pools switched off."""
     path = os.path.join(SC, "bunny_cornell.txt")
     res, depth = (200, 168), 6
     o = orc.Scene(path, res=res, depth=depth)
     ref = np.zeros((o.P, 3), np.float32); lives = []
     for it in (1, 2, 3, 4):
         lives.append(o.pathtrace(MODES[mode], it, ref)[1].copy())
-    for pool in ("0", "64", "512", "2048"):
-        monkeypatch.setenv("PTK_WIDE_POOL", pool)
-        for lanes in (1, 3):
+    for pool, s16 in (("0", "1"), ("64", "1"), ("512", "1"), ("512", "0"), ("2048", "1"), ("2048", "0")):      # (s16: 16-bit per-ray stacks, the choice for trees below 32 768 nodes / leaves; 0 = the 32-bit form larger trees get)
+        monkeypatch.setenv("PTK_WIDE_POOL", pool); monkeypatch.setenv("PTK_POOL_S16", s16)
+        for lanes in (1, 4):
             s = ptk.Scene(path, res=res, depth=depth)
             r = ptk.Renderer(s, MODES[mode], pipeline=pipeline, in_flight=lanes, graph=lanes > 1)
             got = []
             for it in (1, 2, 3, 4):
                 r.iterate(it); got.append(r.live_counts()[0].copy())
             img = r.image(); r.close(); s.close()
-            assert np.array_equal(np.stack(got), np.stack(lives)), (pool, lanes)
-            assert np.array_equal(img, ref), (pool, lanes, int((img != ref).any(axis=1).sum()))
+            assert np.array_equal(np.stack(got), np.stack(lives)), (pool, s16, lanes)
+            assert np.array_equal(img, ref), (pool, s16, lanes, int((img != ref).any(axis=1).sum()))
 
 
 @pytest.mark.parametrize("mode,pipeline", [("BSDF", 0), ("MIS", 0), ("BSDF", 6)])
