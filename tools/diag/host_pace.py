@@ -1,5 +1,8 @@
+"""GPU box: is the render loop paced by the host?  Steady state: 1 024 calls after 64 warm-up calls; prints Grays/s, the time per iteration and the host loop's time per
+call; with PTK_HOST_TIMING=1 the library adds where the host time goes (hipGraphLaunch / the merge's runtime calls / the rest) when the context is freed.
+usage: [PTK_HOST_TIMING=1] host_pace.py scene,mode,lanes[,graph[,W,H[,depth]]] ..."""
 import importlib, os, sys, time
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 ptk = importlib.import_module("project3-cuda-path-tracer-1_amd")
 for case in sys.argv[1:]:
