@@ -44,7 +44,11 @@ __device__ unsigned long long g_phase_buf[2][PTK_PHASE_SLOTS][8];      // per ke
 #define PTK_PHASE(K) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
     if ((threadIdx.x & 63) == 0) g_phase_buf[K][ph_slot][ph_k] += ph_now - ph_prev; ph_prev = __builtin_amdgcn_s_memtime(); ++ph_k; } while (0)
 #define PTK_PHASE_END(K) do { if ((threadIdx.x & 63) == 0) g_phase_buf[K][ph_slot][7] += 1ull; } while (0)
+// (k_tail, end of round 5) a stamp into a FIXED phase index: the phases repeat per bounce
+#define PTK_PHASE_AT(K, IDX) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) g_phase_buf[K][ph_slot][IDX] += ph_now - ph_prev; ph_prev = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define PTK_PHASE_AT(K, IDX) do {} while (0)
 #define PTK_PHASE_BEGIN() do {} while (0)
 #define PTK_PHASE(K) do {} while (0)
 #define PTK_PHASE_END(K) do {} while (0)
@@ -2601,6 +2605,8 @@ template <int MODE>
 __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A) {
     constexpr int NT = PTK_TAIL_BLOCK;
     __shared__ DevMaterial s_mats[PTK_LDS_MATS];
+    PTK_PHASE_BEGIN();                                            // (diagnostic build: phase stamps of WAVE 0 — the wave that holds a bounce of a few dozen paths — in slot 1 of the phase buffer; the other waves' go to slot 0)
+    const int TK = threadIdx.x < 64 ? 1 : 0; (void)TK;
     const GeomStage gs = stage_geoms(S);
     const MatTable mt = stage_materials<NT>(S, s_mats);
     const int step = A.iter_ptr ? *A.iter_ptr : A.iter_arg;
@@ -2609,6 +2615,7 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
     Gather G = A.G;
     int n = A.hit_dense ? *A.nhits : A.counts[A.depth0];        // paths to look at in the first bounce: its hits (hit-dense) or its live paths
     const int crow = cum_row(step, A.ring_div, A.cum_stride);
+    PTK_PHASE_AT(TK, 0);                                           // 0: staging (primitives, materials)
     for (int depth = A.depth0; depth < A.trace_depth; ++depth) {
         const Film img = {A.film, depth};
         if (n <= 0) {                                            // nothing left: the remaining bounces are empty
@@ -2636,9 +2643,10 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
                     int k = 0, base = A.hit_pref[w0];
                     while (k < 4 && i >= A.hit_pref[w0 + k + 1]) { ++k; base = A.hit_pref[w0 + k]; }
                     if (k == 4) k = sparse_window(A.hit_pref, w0 + 4, nw, i, base) - w0;
-                    const int at = (w0 + k) * A.win + (i - base);
+                    const int w = w0 + k;
+                    const int at = w * A.win + (i - base);
                     const int word = (A.compact ? __float_as_int(A.hits0.t_n[4 * (size_t)at + 3]) : A.hr0[at]) & 0x3fffffff;
-                    src = (w0 + k) * A.win + (word & 0xff);
+                    src = w * A.win + (word & 0xff);
                 } else src = gather_source(G, i / PTK_BLOCK, i, n, G.pref ? (*A.nshaded + PTK_BLOCK - 1) / PTK_BLOCK : 0);
                 if (traced && A.compact) {                                  // k_shade_trace's compact streams: (d, pix) (col, bounces) (n, rank) (p, mat)
                     const float4 a4 = ld4(cur.o_pix, src), b4 = ld4(cur.d_bnc, src), h0 = ld4(A.hits0.t_n, src);
@@ -2668,16 +2676,22 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
                         h.uv.x = h2.x; h.uv.y = h2.y; h.geom = __float_as_int(h2.z); h.tri = __float_as_int(h2.w);
                     }
                 } else {
+                    PTK_PHASE_AT(TK, 1);                           // 1: gather + path loads
                     flag = closest_hit<false>(S, gs, p.o, p.d, h, nv, nt);
                     if (!flag && S.env_tex >= 0) add_radiance(img, p.pix, nan_to_zero(p.col * env_radiance(S, p.d)));   // pathtrace.cu:303-311
+                    PTK_PHASE_AT(TK, 2);                           // 2: closest hit
                 }
                 }
             }
+            PTK_PHASE_AT(TK, 1);                                   // 1: gather + loads (traced bounce: incl. the hit record)
             int total;
             const int local = block_excl_prefix_n<NT>(flag, total);
+            PTK_PHASE_AT(TK, 3);                                   // 3: block prefixes
             if (flag) alive = shade_path<MODE>(S, gs, mt, iter, hits_before + local + A.slot_bias + cum_read(A.cum_prev, crow, depth) + (depth >= 1 ? A.dbg_shift_deep : A.dbg_shift0), depth, h, p, img);
+            PTK_PHASE_AT(TK, 4);                                   // 4: shading
             int total2;
             const int local2 = block_excl_prefix_n<NT>(alive, total2);
+            PTK_PHASE_AT(TK, 3);
             if (alive) {
                 const int s = survivors + local2;
                 st4(nxt.o_pix, s, make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.pix)));
@@ -2693,11 +2707,16 @@ __global__ void __launch_bounds__(PTK_TAIL_BLOCK) k_tail(SceneView S, TailArgs A
             if (A.ray_total && !(A.have_hits && depth == A.depth0)) atomicAdd(A.ray_total, (unsigned long long)n);     // (counted by the launch that traced it)
         }
         __syncthreads();                                         // this bounce's stores are visible to the whole workgroup before the next bounce reads them
+        PTK_PHASE_AT(TK, 5);                                       // 5: survivor stores, counts, end-of-bounce barrier
         const PtkPaths t = cur; cur = nxt; nxt = t;
         G.pref = nullptr; G.first = nullptr; G.src = nullptr;   // survivors were written densely
         n = survivors;
+#ifdef PTK_PHASE_TIMING
+        if ((threadIdx.x & 63) == 0) g_phase_buf[TK][ph_slot][6] += 1ull;      // 6: bounces run
+#endif
     }
     if (threadIdx.x == 0 && A.iter_advance) *A.iter_advance += A.iter_stride;
+    PTK_PHASE_END(TK);
 }
 
 // stand-alone form of segments_block (one block; used when the shading kernel does not run the tail itself)
