@@ -233,6 +233,28 @@ def test_batched_ordered_merge(ptk, orc, torch_cuda, monkeypatch, name, res, dep
         assert np.array_equal(img, ref), (batch, int((img != ref).any(axis=1).sum()))
 
 
+@pytest.mark.parametrize("name,res,depth,mode", [("cornell.txt", (200, 168), 8, "MIS"), ("mis_test.txt", (256, 256), 16, "BSDF"), ("bunny_cornell.txt", (96, 96), 5, "MIS")])
+def test_merge_stream(ptk, orc, torch_cuda, monkeypatch, name, res, depth, mode):
+    """End of round 5 (opt-in PTK_MERGE_STREAM=1; measured slower — two cross-queue event edges per iteration instead of one, profiles/r5_ab_lane_queues.txt): every
+    merge on one stream of its own, lanes alternate between two plane sets and never wait for a merge.  The image stays the reference's running sum, bit for bit —
+    also when it is read in the middle of the sequence (the reader joins the merge stream) and when the caller jumps in the call sequence."""
+    monkeypatch.setenv("PTK_MERGE_STREAM", "1")
+    m = MODES[mode]
+    o = orc.Scene(os.path.join(SC, name), res=res, depth=depth)
+    ref = np.zeros((o.P, 3), np.float32); mid = None
+    seq = [1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15]
+    for k, it in enumerate(seq):
+        o.pathtrace(m, it, ref)
+        if k == 5: mid = ref.copy()
+    s = ptk.Scene(os.path.join(SC, name), res=res, depth=depth)
+    r = ptk.Renderer(s, m, in_flight=4, graph=True)
+    for k, it in enumerate(seq):
+        r.iterate(it)
+        if k == 5: assert np.array_equal(r.image(), mid)
+    img = r.image(); r.close(); s.close()
+    assert np.array_equal(img, ref), int((img != ref).any(axis=1).sum())
+
+
 @pytest.mark.parametrize("name,res,depth,mode,lanes", [("cornell.txt", (200, 168), 8, "BSDF", 3), ("cornell.txt", (131, 77), 6, "MIS", 1), ("mis_test.txt", (256, 256), 16, "MIS", 3),
                                                        ("mis_test2.txt", (216, 216), 8, "DIRECT", 1), ("metallic_analytic.txt", (160, 160), 8, "MIS", 3)])
 def test_wave_windows(ptk, orc, torch_cuda, monkeypatch, name, res, depth, mode, lanes):
